@@ -1,0 +1,215 @@
+"""ctypes binding of libavd_hip.so (C-ABI declared in include/avd.h).
+
+The library is built in-tree by ``make -C ai-video-detector_amd/csrc`` (or
+``__graft_entry__.build()``).  There is no CPU fallback: if the shared object is
+missing, or no HIP device is usable, loading / context creation raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(_PKG, "csrc")
+SO_PATH = os.path.join(_PKG, "lib", "libavd_hip.so")
+
+AVD_MEM_HOST, AVD_MEM_DEVICE = 0, 1
+SMALL, HASH = 320, 32
+
+EXPORTS = (
+    "avd_abi_version", "avd_create", "avd_destroy", "avd_last_error",
+    "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
+    "avd_analyze_frames_async", "avd_synchronize", "avd_timer_start", "avd_timer_stop",
+    "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
+)
+
+# numpy view of struct avd_frame_record (32 bytes)
+RECORD_DTYPE = np.dtype([("lap_sum", "<i8"), ("lap_sumsq", "<i8"), ("flow_mean", "<f4"),
+                         ("flow_var", "<f4"), ("ham", "<i4"), ("reserved", "<i4")])
+
+
+class AvdError(RuntimeError):
+    """Non-zero status from the C-ABI (the analyzer may raise; reference api.py:134-140
+    turns any exception into the neutral 0.5 timeline)."""
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "avd.h"))
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: build it with `make -C {CSRC}` "
+                          "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(SO_PATH)
+    vp, u8p, f32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.avd_abi_version.restype = C.c_int
+    L.avd_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.avd_destroy.argtypes = [vp]
+    L.avd_destroy.restype = None
+    L.avd_last_error.argtypes = [vp]
+    L.avd_last_error.restype = C.c_char_p
+    L.avd_preprocess_bgr.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                     u8p, u8p, i64p, i64p]
+    L.avd_farneback_pairs.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, f32p, f32p]
+    L.avd_analyze_frames.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp]
+    L.avd_analyze_frames_async.argtypes = L.avd_analyze_frames.argtypes
+    L.avd_synchronize.argtypes = [vp]
+    L.avd_timer_start.argtypes = [vp]
+    L.avd_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.avd_set_profiling.argtypes = [vp, C.c_int]
+    L.avd_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.avd_debug_fetch.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    L.avd_debug_fetch.restype = C.c_int64
+    for name in EXPORTS:
+        if name not in ("avd_destroy", "avd_last_error", "avd_debug_fetch"):
+            getattr(L, name).restype = C.c_int
+    if L.avd_abi_version() != 1:
+        raise ImportError("libavd_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class Context:
+    """One avd_ctx: one device, one HIP stream, one workspace.  Not re-entrant -- use one
+    Context per thread (ctypes releases the GIL for the duration of each call)."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.avd_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise AvdError(f"avd_create(device={device}) failed with status {rc}: no usable HIP device "
+                           "(the HIP path has no CPU fallback)")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.avd_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._L.avd_last_error(self._h)
+            raise AvdError(f"avd status {rc}: {msg.decode() if msg else ''}")
+
+    # -- buffers: numpy (host) or torch-ROCm tensors (device) ----------------------------
+    @staticmethod
+    def _frames_ptr(frames):
+        """-> (ptr, mem, n, h, w, row_stride, frame_stride, keepalive)"""
+        if _is_torch_tensor(frames):
+            t = frames
+            if t.dim() != 4 or t.shape[-1] != 3 or str(t.dtype) != "torch.uint8":
+                raise ValueError("frames must be uint8[N,H,W,3] (BGR)")
+            if t.stride(-1) != 1 or t.stride(-2) != 3:
+                t = t.contiguous()
+            n, h, w, _ = t.shape
+            mem = AVD_MEM_DEVICE if t.is_cuda else AVD_MEM_HOST
+            fs = t.stride(0) if n > 1 else h * t.stride(1)
+            return t.data_ptr(), mem, n, h, w, t.stride(1), fs, t
+        a = np.asarray(frames)
+        if a.ndim != 4 or a.shape[-1] != 3 or a.dtype != np.uint8:
+            raise ValueError("frames must be uint8[N,H,W,3] (BGR)")
+        if a.strides[-1] != 1 or a.strides[-2] != 3 or a.strides[1] < a.shape[2] * 3 or (
+                a.shape[0] > 1 and a.strides[0] < a.strides[1] * a.shape[1]):
+            a = np.ascontiguousarray(a)
+        n, h, w, _ = a.shape
+        fs = a.strides[0] if n > 1 else h * a.strides[1]
+        return a.ctypes.data, AVD_MEM_HOST, n, h, w, a.strides[1], fs, a
+
+    def preprocess_bgr(self, frames):
+        ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
+        small = np.empty((n, SMALL, SMALL), np.uint8)
+        hsh = np.empty((n, HASH * HASH), np.uint8)
+        s = np.empty(n, np.int64)
+        q = np.empty(n, np.int64)
+        self._check(self._L.avd_preprocess_bgr(self._h, ptr, mem, n, h, w, rs, fs, small.ctypes.data,
+                                               hsh.ctypes.data, s.ctypes.data, q.ctypes.data))
+        return small, hsh, s, q
+
+    def farneback_pairs(self, small, want_flow: bool = False):
+        if _is_torch_tensor(small):
+            t = small.contiguous()
+            ptr, mem, n, keep = t.data_ptr(), (AVD_MEM_DEVICE if t.is_cuda else AVD_MEM_HOST), t.shape[0], t
+        else:
+            a = np.ascontiguousarray(small, dtype=np.uint8)
+            ptr, mem, n, keep = a.ctypes.data, AVD_MEM_HOST, a.shape[0], a
+        m = max(n - 1, 0)
+        fm = np.zeros(m, np.float32)
+        fv = np.zeros(m, np.float32)
+        flow = np.empty((m, SMALL, SMALL, 2), np.float32) if want_flow else None
+        self._check(self._L.avd_farneback_pairs(self._h, ptr, mem, n, fm.ctypes.data, fv.ctypes.data,
+                                                flow.ctypes.data if want_flow else None))
+        return (fm, fv, flow) if want_flow else (fm, fv)
+
+    def analyze_frames(self, frames) -> np.ndarray:
+        """-> structured array (RECORD_DTYPE) with one record per frame."""
+        ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
+        rec = np.zeros(n, RECORD_DTYPE)
+        self._check(self._L.avd_analyze_frames(self._h, ptr, mem, n, h, w, rs, fs, rec.ctypes.data))
+        return rec
+
+    def analyze_frames_async(self, frames, rec: np.ndarray):
+        ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
+        assert rec.dtype == RECORD_DTYPE and rec.size >= n and rec.flags.c_contiguous
+        self._check(self._L.avd_analyze_frames_async(self._h, ptr, mem, n, h, w, rs, fs, rec.ctypes.data))
+        return keep
+
+    def synchronize(self):
+        self._check(self._L.avd_synchronize(self._h))
+
+    def timer_start(self):
+        self._check(self._L.avd_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self._L.avd_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def set_profiling(self, on: bool):
+        self._check(self._L.avd_set_profiling(self._h, int(bool(on))))
+
+    def stage_ms(self):
+        out = []
+        for i in range(4):
+            ms = C.c_float()
+            self._check(self._L.avd_stage_ms(self._h, i, C.byref(ms)))
+            out.append(float(ms.value))
+        return out
+
+    def debug_fetch(self, name: str, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        got = self._L.avd_debug_fetch(self._h, name.encode(), out.ctypes.data, out.nbytes)
+        if got < 0:
+            self._check(int(got))
+        if got != out.nbytes:
+            raise AvdError(f"debug buffer {name}: expected {out.nbytes} bytes, got {got}")
+        return out

@@ -1,0 +1,438 @@
+// avd_capi.hip -- C-ABI of libavd_hip.so (include/avd.h): context, workspace, entry points.
+// Host C++; every kernel lives in avd_preprocess.hip / avd_farneback.hip.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include "avd_internal.h"
+
+namespace {
+
+constexpr int kFbChunk = 128;      // Farneback pairs per workspace chunk (bounds HBM scratch)
+
+template <typename T>
+int dev_alloc(avd_ctx* ctx, T*& p, size_t count)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        p = nullptr;
+        return AVD_ERR_NOMEM;
+    }
+    return 0;
+}
+
+int rows_per_band_for(int w)
+{
+    // LDS tile = (rows+2) * pitch bytes, kept under 48 KiB so that >= 3 workgroups fit a CU
+    const int pitch = ((w + 32 + 15) / 16) * 16;
+    int r = (48 * 1024) / pitch - 2;
+    r = std::min(r, 16);
+    return std::max(r, 1);
+}
+
+struct TableBlob {
+    std::vector<uint8_t> bytes;
+    template <typename T>
+    size_t push(const std::vector<T>& v)
+    {
+        size_t off = (bytes.size() + 15) / 16 * 16;
+        bytes.resize(off + v.size() * sizeof(T));
+        std::memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+};
+
+void free_ws(Workspace& ws)
+{
+    auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap);
+    F(ws.d_tables);
+    for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
+    F(ws.d_tmp); F(ws.d_M[0]); F(ws.d_M[1]); F(ws.d_vs); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_rec);
+    if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
+    ws = Workspace{};
+}
+
+int check_geometry(avd_ctx* ctx, int n, int h, int w, int64_t row_stride, int64_t frame_stride)
+{
+    if (n < 0 || h <= 0 || w <= 0 || h > 16384 || w > 16384) { ctx->err = "bad frame geometry"; return AVD_ERR_ARG; }
+    if (row_stride < (int64_t)w * 3 || (n > 1 && frame_stride < row_stride * (h - 1) + (int64_t)w * 3)) {
+        ctx->err = "strides smaller than the frame"; return AVD_ERR_ARG;
+    }
+    if (h < AVD_HASH || w < AVD_HASH) { ctx->err = "frame smaller than 32x32: INTER_AREA upscaling is not on the path"; return AVD_ERR_UNSUPPORTED; }
+    return 0;
+}
+
+}  // namespace
+
+// ---- workspace -----------------------------------------------------------------------
+int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
+{
+    Workspace& ws = ctx->ws;
+    const bool geom_changed = ws.h != h || ws.w != w;
+    if (geom_changed) {
+        LinearTab lt;
+        AreaTab at;
+        build_linear_tab(h, w, AVD_SMALL, AVD_SMALL, lt);
+        int rc = build_area_tab(h, w, AVD_HASH, AVD_HASH, at);
+        if (rc) { ctx->err = "unsupported geometry for INTER_AREA"; return rc; }
+        const int R = rows_per_band_for(w);
+        const int nbands = (h + R - 1) / R;
+        std::vector<int> band_dy(nbands + 1, AVD_SMALL);
+        for (int b = 0; b <= nbands; b++) {
+            int d = 0;
+            while (d < AVD_SMALL && lt.y0[d] < b * R) d++;
+            band_dy[b] = d;
+        }
+        band_dy[nbands] = AVD_SMALL;
+        TableBlob tb;
+        const size_t o_lx0 = tb.push(lt.x0), o_lx1 = tb.push(lt.x1), o_ly0 = tb.push(lt.y0), o_ly1 = tb.push(lt.y1);
+        const size_t o_la0 = tb.push(lt.a0), o_la1 = tb.push(lt.a1), o_lb0 = tb.push(lt.b0), o_lb1 = tb.push(lt.b1);
+        const size_t o_band = tb.push(band_dy);
+        const size_t o_axb = tb.push(at.x.begin), o_axc = tb.push(at.x.count);
+        const size_t o_axf = tb.push(at.x.w_first), o_axm = tb.push(at.x.w_mid), o_axl = tb.push(at.x.w_last);
+        const size_t o_ayb = tb.push(at.y.begin), o_ayc = tb.push(at.y.count);
+        const size_t o_ayf = tb.push(at.y.w_first), o_aym = tb.push(at.y.w_mid), o_ayl = tb.push(at.y.w_last);
+        uint8_t* dt = (uint8_t*)ws.d_tables;
+        if (int e = dev_alloc(ctx, dt, tb.bytes.size())) return e;
+        ws.d_tables = dt; ws.tables_bytes = tb.bytes.size();
+        HIP_TRY(ctx, hipMemcpyAsync(dt, tb.bytes.data(), tb.bytes.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // tb goes out of scope
+        PreParams& P = ws.pre;
+        P.lx0 = (const int*)(dt + o_lx0); P.lx1 = (const int*)(dt + o_lx1);
+        P.ly0 = (const int*)(dt + o_ly0); P.ly1 = (const int*)(dt + o_ly1);
+        P.la0 = (const short*)(dt + o_la0); P.la1 = (const short*)(dt + o_la1);
+        P.lb0 = (const short*)(dt + o_lb0); P.lb1 = (const short*)(dt + o_lb1);
+        P.band_dy = (const int*)(dt + o_band);
+        P.ax_begin = (const int*)(dt + o_axb); P.ax_count = (const int*)(dt + o_axc);
+        P.ax_first = (const float*)(dt + o_axf); P.ax_mid = (const float*)(dt + o_axm); P.ax_last = (const float*)(dt + o_axl);
+        P.area_fast = at.fast;
+        P.h = h; P.w = w; P.rows_per_band = R; P.nbands = nbands;
+        P.pitch = ((w + 32 + 15) / 16) * 16;
+        HashParams& H = ws.hsh;
+        H.ay_begin = (const int*)(dt + o_ayb); H.ay_count = (const int*)(dt + o_ayc);
+        H.ay_first = (const float*)(dt + o_ayf); H.ay_mid = (const float*)(dt + o_aym); H.ay_last = (const float*)(dt + o_ayl);
+        H.area_fast = at.fast;
+        H.fast_area = at.iscale_x * at.iscale_y;
+        H.fast_simd_w = (at.fast && at.iscale_x == 2 && at.iscale_y == 2) ? (AVD_HASH & ~7) : 0;
+        H.h = h;
+    }
+    if (geom_changed || n > ws.cap_n) {
+        const int cap = std::max(n, 1);
+        if (int e = dev_alloc(ctx, ws.d_small, (size_t)cap * AVD_NPIX)) return e;
+        if (int e = dev_alloc(ctx, ws.d_rowbuf, (size_t)cap * h * AVD_HASH)) return e;
+        if (int e = dev_alloc(ctx, ws.d_area, (size_t)cap * 1024)) return e;
+        if (int e = dev_alloc(ctx, ws.d_hash, (size_t)cap * 1024)) return e;
+        if (int e = dev_alloc(ctx, ws.d_ham, (size_t)cap)) return e;
+        if (int e = dev_alloc(ctx, ws.d_lap, (size_t)cap * 2)) return e;
+        if (int e = dev_alloc(ctx, ws.d_rec, (size_t)cap)) return e;
+        if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
+        HIP_TRY(ctx, hipHostMalloc((void**)&ws.h_rec, sizeof(avd_frame_record) * cap, hipHostMallocDefault));
+        ws.cap_n = cap; ws.h = h; ws.w = w;
+    }
+    return 0;
+}
+
+// Farneback scratch for up to kFbChunk pairs (kFbChunk+1 frames)
+int avd_ws_reserve_fb(avd_ctx* ctx, int n)
+{
+    Workspace& ws = ctx->ws;
+    if (ws.d_vs) return 0;
+    const size_t nf = kFbChunk + 1, np = kFbChunk;
+    for (int k = 0; k < AVD_FB_LEVELS; k++) {
+        const size_t plane = (size_t)(AVD_SMALL >> k) * (AVD_SMALL >> k);
+        if (int e = dev_alloc(ctx, ws.d_pyr[k], nf * plane)) return e;
+        if (int e = dev_alloc(ctx, ws.d_poly[k], nf * 5 * plane)) return e;
+        if (int e = dev_alloc(ctx, ws.d_flow[k], np * 2 * plane)) return e;
+    }
+    if (int e = dev_alloc(ctx, ws.d_tmp, nf * AVD_NPIX)) return e;
+    if (int e = dev_alloc(ctx, ws.d_M[0], np * 5 * AVD_NPIX)) return e;
+    if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
+    if (int e = dev_alloc(ctx, ws.d_vs, np * 5 * AVD_NPIX)) return e;
+    (void)n;
+    return 0;
+}
+
+// ---- record assembly -------------------------------------------------------------------
+__global__ void k_records(const unsigned long long* lap, const int* ham, const float* stats, int stats_off,
+                          avd_frame_record* rec, int f0, int count, int write_pre, int write_flow)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int f = f0 + i;
+    if (write_pre) {
+        rec[f].lap_sum = (int64_t)lap[2 * f];
+        rec[f].lap_sumsq = (int64_t)lap[2 * f + 1];
+        rec[f].ham = ham[f];
+        rec[f].reserved = 0;
+        if (f == 0) { rec[f].flow_mean = 0.f; rec[f].flow_var = 0.f; }
+    }
+    if (write_flow && f > 0) {
+        rec[f].flow_mean = stats[2 * (f - 1 - stats_off)];
+        rec[f].flow_var = stats[2 * (f - 1 - stats_off) + 1];
+    }
+}
+
+// Farneback + stats over all n-1 pairs in chunks; pair p = (frame p, frame p+1).
+static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h_mean, float* h_var,
+                           float* h_flow_out, bool into_records)
+{
+    Workspace& ws = ctx->ws;
+    if (n < 2) return 0;
+    if (int e = avd_ws_reserve_fb(ctx, n)) return e;
+    if (h_flow_out && !ws.d_flow_il)
+        if (int e = dev_alloc(ctx, ws.d_flow_il, (size_t)kFbChunk * AVD_NPIX * 2)) return e;
+    float* saved_il = ws.d_flow_il;
+    if (!h_flow_out) ws.d_flow_il = nullptr;
+    int rc = 0;
+    for (int p0 = 0; p0 < n - 1 && rc == 0; p0 += kFbChunk) {
+        const int np = std::min(kFbChunk, n - 1 - p0);
+        rc = launch_farneback(ctx, d_small + (size_t)p0 * AVD_NPIX, np + 1);
+        if (rc) break;
+        rc = launch_flow_stats(ctx, np + 1);
+        if (rc) break;
+        if (into_records) {
+            hipLaunchKernelGGL(k_records, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
+                               (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats,
+                               p0, ws.d_rec, p0 + 1, np, 0, 1);
+        }
+        if (h_mean || h_var || h_flow_out) {
+            std::vector<float> st((size_t)np * 2);
+            hipError_t e = hipMemcpyAsync(st.data(), ws.d_stats, sizeof(float) * 2 * np, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess && h_flow_out)
+                e = hipMemcpyAsync(h_flow_out + (size_t)p0 * AVD_NPIX * 2, ws.d_flow_il,
+                                   sizeof(float) * 2 * AVD_NPIX * np, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = AVD_ERR_DEVICE; break; }
+            for (int i = 0; i < np; i++) {
+                if (h_mean) h_mean[p0 + i] = st[2 * i];
+                if (h_var) h_var[p0 + i] = st[2 * i + 1];
+            }
+        }
+    }
+    ws.d_flow_il = saved_il;
+    return rc;
+}
+
+// Make `src` (host or device) available on the device; host input is staged over PCIe.
+static int stage_input(avd_ctx* ctx, const uint8_t* src, int mem, size_t bytes, const uint8_t** d_out)
+{
+    if (mem == AVD_MEM_DEVICE) { *d_out = src; return 0; }
+    if (mem != AVD_MEM_HOST) { ctx->err = "mem must be AVD_MEM_HOST or AVD_MEM_DEVICE"; return AVD_ERR_ARG; }
+    Workspace& ws = ctx->ws;
+    if (ws.stage_bytes < bytes) {
+        if (int e = dev_alloc(ctx, ws.d_stage, bytes)) return e;
+        ws.stage_bytes = bytes;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_stage, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *d_out = ws.d_stage;
+    return 0;
+}
+
+static void stage_mark(avd_ctx* ctx, int i)
+{
+    if (ctx->profiling) (void)hipEventRecord(ctx->stage_ev[i], ctx->stream);
+}
+
+// ---- C-ABI ------------------------------------------------------------------------------
+extern "C" {
+
+int avd_abi_version(void) { return AVD_ABI_VERSION; }
+
+int avd_create(int device_id, avd_ctx** out)
+{
+    if (!out) return AVD_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count)
+        return AVD_ERR_DEVICE;
+    avd_ctx* ctx = new (std::nothrow) avd_ctx();
+    if (!ctx) return AVD_ERR_NOMEM;
+    ctx->device = device_id;
+    bool ok = hipSetDevice(device_id) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+    for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
+    if (ok) {
+        build_fb_consts(ctx->fbc);
+        ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
+             hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { avd_destroy(ctx); return AVD_ERR_DEVICE; }
+    *out = ctx;
+    return AVD_OK;
+}
+
+void avd_destroy(avd_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_ws(ctx->ws);
+    if (ctx->d_fbc) (void)hipFree(ctx->d_fbc);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* avd_last_error(const avd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int avd_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                       int64_t row_stride, int64_t frame_stride,
+                       uint8_t* small320, uint8_t* hash1024, int64_t* lap_sum, int64_t* lap_sumsq)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (!bgr && n > 0) { ctx->err = "null frame pointer"; return AVD_ERR_ARG; }
+    if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
+    if (n == 0) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
+    const uint8_t* d_bgr = nullptr;
+    const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
+    if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
+    if (int e = launch_preprocess(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
+    if (int e = launch_hash(ctx, n)) return e;
+    Workspace& ws = ctx->ws;
+    std::vector<unsigned long long> lap((size_t)n * 2);
+    if (small320) HIP_TRY(ctx, hipMemcpyAsync(small320, ws.d_small, (size_t)n * AVD_NPIX, hipMemcpyDeviceToHost, ctx->stream));
+    if (hash1024) HIP_TRY(ctx, hipMemcpyAsync(hash1024, ws.d_hash, (size_t)n * 1024, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lap.data(), ws.d_lap, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++) {
+        if (lap_sum) lap_sum[f] = (int64_t)lap[2 * f];
+        if (lap_sumsq) lap_sumsq[f] = (int64_t)lap[2 * f + 1];
+    }
+    ctx->last_n = n;
+    return AVD_OK;
+}
+
+int avd_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, int n,
+                        float* flow_mean, float* flow_var, float* flow_out)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (n < 0 || (!small320 && n > 0)) { ctx->err = "bad arguments"; return AVD_ERR_ARG; }
+    if (n < 2) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint8_t* d_small = nullptr;
+    if (int e = stage_input(ctx, small320, mem, (size_t)n * AVD_NPIX, &d_small)) return e;
+    if (int e = run_flow_chunks(ctx, d_small, n, flow_mean, flow_var, flow_out, false)) return e;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_n = std::min(n, kFbChunk + 1);
+    return AVD_OK;
+}
+
+int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                             int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if ((!bgr || !records) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
+    if (n == 0) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
+    if (int e = avd_ws_reserve_fb(ctx, n)) return e;
+    const uint8_t* d_bgr = nullptr;
+    const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
+    if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
+    Workspace& ws = ctx->ws;
+    stage_mark(ctx, 0);
+    if (int e = launch_preprocess(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
+    stage_mark(ctx, 1);
+    if (int e = launch_hash(ctx, n)) return e;
+    hipLaunchKernelGGL(k_records, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats, 0,
+                       ws.d_rec, 0, n, 1, 0);
+    stage_mark(ctx, 2);
+    if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true)) return e;
+    stage_mark(ctx, 3);
+    HIP_TRY(ctx, hipMemcpyAsync(records, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
+    stage_mark(ctx, 4);
+    ctx->last_n = n;
+    return AVD_OK;
+}
+
+int avd_synchronize(avd_ctx* ctx)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        // stages: 0 preprocess, 1 hash+hamming+records, 2 farneback+stats (3 reported as copy-out)
+        for (int i = 0; i < 4; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->stage_ev[i], ctx->stage_ev[i + 1]) == hipSuccess) ctx->stage_ms[i] = ms;
+        }
+    }
+    return AVD_OK;
+}
+
+int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                       int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
+{
+    int rc = avd_analyze_frames_async(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records);
+    if (rc) return rc;
+    return avd_synchronize(ctx);
+}
+
+int avd_timer_start(avd_ctx* ctx)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return AVD_OK;
+}
+
+int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return AVD_ERR_ARG;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return AVD_OK;
+}
+
+int avd_set_profiling(avd_ctx* ctx, int enable)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    ctx->profiling = enable != 0;
+    return AVD_OK;
+}
+
+int avd_stage_ms(avd_ctx* ctx, int stage, float* ms)
+{
+    if (!ctx || !ms || stage < 0 || stage > 3) return AVD_ERR_ARG;
+    *ms = ctx->stage_ms[stage];
+    return AVD_OK;
+}
+
+int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes)
+{
+    if (!ctx || !name || !out) return AVD_ERR_ARG;
+    Workspace& ws = ctx->ws;
+    const int n = ctx->last_n;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    auto level = [&](const char* prefix) -> int {
+        const size_t L = std::strlen(prefix);
+        if (std::strncmp(name, prefix, L) == 0 && name[L] >= '0' && name[L] < '0' + AVD_FB_LEVELS && name[L + 1] == 0)
+            return name[L] - '0';
+        return -1;
+    };
+    int k;
+    if (std::strcmp(name, "area") == 0) { src = ws.d_area; bytes = (size_t)n * 1024; }
+    else if (std::strcmp(name, "small") == 0) { src = ws.d_small; bytes = (size_t)n * AVD_NPIX; }
+    else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)n * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)n * 5 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("flow")) >= 0) { src = ws.d_flow[k]; bytes = (size_t)std::max(n - 1, 0) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
+    else { ctx->err = "unknown debug buffer"; return AVD_ERR_ARG; }
+    if (!src) { ctx->err = "buffer not allocated yet"; return AVD_ERR_ARG; }
+    bytes = std::min(bytes, out_bytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    return (int64_t)bytes;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// avd_internal.h -- shared declarations of libavd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/avd.h"
+
+#define AVD_FB_LEVELS 4            // pyramid scales 1/8,1/4,1/2,1 of 320 (see farneback.hip)
+#define AVD_NPIX (AVD_SMALL * AVD_SMALL)
+
+#define HIP_TRY(ctx, expr)                                                         \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);       \
+            return AVD_ERR_DEVICE;                                                 \
+        }                                                                          \
+    } while (0)
+
+// ---- host-built resampling tables (avd_tables.cpp) ------------------------------
+// INTER_LINEAR uint8 -> 320x320 (cv2.resize default, reference video.py:43)
+struct LinearTab {
+    std::vector<int> x0, x1, y0, y1;          // clipped source indices
+    std::vector<short> a0, a1, b0, b1;        // 11-bit fixed-point weights
+};
+void build_linear_tab(int src_h, int src_w, int dst_h, int dst_w, LinearTab& t);
+
+// INTER_AREA uint8 -> 32x32 (reference video.py:6): per destination index a run of
+// consecutive source indices with (first, middle, last) float weights.
+struct AreaAxis {
+    std::vector<int> begin, count;
+    std::vector<float> w_first, w_mid, w_last;
+};
+struct AreaTab {
+    AreaAxis x, y;
+    int fast;          // both scales integral: integer box sums (ResizeAreaFast)
+    int iscale_x, iscale_y;
+};
+int build_area_tab(int src_h, int src_w, int dst_h, int dst_w, AreaTab& t);   // <0: unsupported
+
+// Farneback constant tables (polynomial expansion kernels, pyramid Gaussian kernels)
+struct FbConsts {
+    float g[11], xg[11], xxg[11];      // centre at index 5 (poly_n = 5)
+    double ig11, ig03, ig33, ig55;
+    float gk[AVD_FB_LEVELS][19];       // per-level Gaussian taps, level index = pyramid k
+    int gksize[AVD_FB_LEVELS];
+};
+void build_fb_consts(FbConsts& c);
+
+// ---- device-side parameter blocks ------------------------------------------------
+struct PreParams {
+    // linear 320
+    const int *lx0, *lx1, *ly0, *ly1;
+    const short *la0, *la1, *lb0, *lb1;
+    const int* band_dy;                // [nbands+1] first dy owned by each band
+    // area x axis (32 entries)
+    const int *ax_begin, *ax_count;
+    const float *ax_first, *ax_mid, *ax_last;
+    int area_fast;
+    int h, w, rows_per_band, nbands, pitch;
+    int64_t row_stride, frame_stride;
+};
+
+struct HashParams {
+    const int *ay_begin, *ay_count;
+    const float *ay_first, *ay_mid, *ay_last;
+    int area_fast, fast_area, fast_simd_w;   // fast: integer sums; area = iscale_x*iscale_y
+    int h;
+};
+
+struct Workspace {
+    // geometry the workspace was sized for
+    int cap_n = 0, h = 0, w = 0;
+    // preprocess
+    uint8_t* d_stage = nullptr; size_t stage_bytes = 0;   // staged host frames
+    uint8_t* d_small = nullptr;       // [n][320*320]
+    float* d_rowbuf = nullptr;        // [n][h][32]
+    uint8_t* d_area = nullptr;        // [n][1024]
+    uint8_t* d_hash = nullptr;        // [n][1024]
+    int* d_ham = nullptr;             // [n]
+    unsigned long long* d_lap = nullptr;   // [n][2]
+    void* d_tables = nullptr; size_t tables_bytes = 0;
+    PreParams pre{};
+    HashParams hsh{};
+    // farneback
+    float* d_pyr[AVD_FB_LEVELS] = {};     // [n][hL*wL]
+    float* d_poly[AVD_FB_LEVELS] = {};    // [n][5][hL*wL]
+    float* d_tmp = nullptr;               // row-filtered scratch [n][320*320]
+    float* d_flow[AVD_FB_LEVELS] = {};    // [n-1][2][hL*wL]  planar
+    float* d_M[2] = {};                   // [n-1][5][320*320] (ping-pong)
+    double* d_vs = nullptr;               // [n-1][5][320*320] vertical running sums
+    float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
+    float* d_stats = nullptr;             // [n-1][2] mean, var
+    avd_frame_record* d_rec = nullptr;    // [n]
+    avd_frame_record* h_rec = nullptr;    // pinned [n]
+};
+
+struct avd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t stage_ev[5] = {};
+    int profiling = 0;
+    float stage_ms[4] = {};
+    std::string err;
+    Workspace ws;
+    FbConsts fbc;
+    void* d_fbc = nullptr;          // FbConsts on device
+    int last_n = 0;
+};
+
+// ---- stage launchers (each enqueues on ctx->stream) --------------------------------
+int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w);
+int avd_ws_reserve_fb(avd_ctx* ctx, int n);
+int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
+                      int64_t row_stride, int64_t frame_stride);
+int launch_hash(avd_ctx* ctx, int n);
+int launch_farneback(avd_ctx* ctx, const uint8_t* d_small, int n);
+int launch_flow_stats(avd_ctx* ctx, int n);

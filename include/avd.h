@@ -1,0 +1,123 @@
+/*
+ * avd.h -- C-ABI of libavd_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame video-analysis hot path of backtato/ai-video-detector.
+ *
+ * The reference has no native boundary: its hot path is 82 lines of Python
+ * (reference app/analyzers/video.py:10-83) that call OpenCV per sampled frame.
+ * Each entry point below replaces the OpenCV/numpy calls named beside it; the
+ * Python shim that binds them (ctypes) is ai-video-detector_amd/avd_hip/_lib.py
+ * and the drop-in module is ai-video-detector_amd/app/analyzers/video.py
+ * (same module path / signature as the reference).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures.
+ *   - every function returns 0 on success, a negative avd_status otherwise and
+ *     never throws; avd_last_error(ctx) gives a message owned by ctx.
+ *   - the caller owns every buffer; the library never frees or retains them.
+ *   - `mem` says where an INPUT buffer lives: AVD_MEM_HOST (staged over PCIe) or
+ *     AVD_MEM_DEVICE (already resident in HBM of ctx's device, e.g. a
+ *     torch-ROCm tensor's data_ptr or a hardware decoder surface).
+ *     OUTPUT buffers are always host memory (they are tiny).
+ *   - one avd_ctx = one device, one HIP stream, one workspace.  A ctx is not
+ *     re-entrant: use one ctx per thread (calls on different ctxs run concurrently).
+ *   - if no HIP device is usable avd_create fails (AVD_ERR_DEVICE): there is no
+ *     CPU fallback in this library.
+ */
+#ifndef AVD_H
+#define AVD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct avd_ctx avd_ctx;
+
+enum avd_status {
+    AVD_OK = 0,
+    AVD_ERR_ARG = -1,       /* bad argument (null pointer, size out of range) */
+    AVD_ERR_DEVICE = -2,    /* no usable HIP device / HIP runtime error */
+    AVD_ERR_NOMEM = -3,     /* workspace allocation failed */
+    AVD_ERR_UNSUPPORTED = -4 /* frame smaller than 32x32 (INTER_AREA upscaling) etc. */
+};
+
+enum avd_mem { AVD_MEM_HOST = 0, AVD_MEM_DEVICE = 1 };
+
+#define AVD_SMALL 320          /* video.py:43 resize target */
+#define AVD_HASH 32            /* video.py:36 aHash size */
+#define AVD_ABI_VERSION 1
+
+/* One record per sampled frame: everything video.py:36-57 derives from pixels.
+ * The scalar tail (tex variance, ai_susp, summary, timeline; video.py:54-83) is
+ * O(N) float64 host work done by the caller from these records. */
+typedef struct avd_frame_record {
+    int64_t lap_sum;     /* sum  of cv2.Laplacian(gray, CV_64F)        (video.py:52) */
+    int64_t lap_sumsq;   /* sum of squares of the same (exact integers)            */
+    float   flow_mean;   /* np.mean(|flow|) vs the previous sampled frame (video.py:47); 0 for frame 0 */
+    float   flow_var;    /* np.var(|flow|)                                 (video.py:48); 0 for frame 0 */
+    int32_t ham;         /* popcount(hash ^ prev_hash)     (video.py:38); -1 for frame 0 */
+    int32_t reserved;
+} avd_frame_record;      /* 32 bytes */
+
+int avd_abi_version(void);
+
+/* Lifetime.  avd_create binds HIP device `device_id`, creates a stream.  */
+int avd_create(int device_id, avd_ctx** out);
+void avd_destroy(avd_ctx* ctx);
+const char* avd_last_error(const avd_ctx* ctx);
+
+/* Replaces, for n decoded BGR frames (uint8, interleaved, frame f row y at
+ * bgr + f*frame_stride + y*row_stride):
+ *   cv2.cvtColor(BGR2GRAY) x3, cv2.resize(32x32, INTER_AREA) + mean threshold,
+ *   cv2.resize(320x320) INTER_LINEAR, cv2.Laplacian(CV_64F) moments
+ *   (video.py:4-8, 36, 43, 51-52).
+ * Outputs (host, any may be NULL): small320 uint8[n][320*320], hash1024 uint8[n][1024]
+ * (0/1), lap_sum / lap_sumsq int64[n]. */
+int avd_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                       int64_t row_stride, int64_t frame_stride,
+                       uint8_t* small320, uint8_t* hash1024,
+                       int64_t* lap_sum, int64_t* lap_sumsq);
+
+/* Replaces cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+ * + np.sqrt/np.mean/np.var (video.py:45-48) for the n-1 consecutive pairs of
+ * n 320x320 uint8 images.  Outputs host float[n-1].  flow_out (host, may be
+ * NULL) receives the dense flow float[n-1][320][320][2]. */
+int avd_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, int n,
+                        float* flow_mean, float* flow_var, float* flow_out);
+
+/* The whole per-frame pixel path in one call: preprocess + Hamming + Farneback
+ * + flow statistics, everything resident in HBM in between (video.py:36-52).
+ * records: host avd_frame_record[n]. */
+int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                       int64_t row_stride, int64_t frame_stride,
+                       avd_frame_record* records);
+
+/* Same, but only enqueues the work on ctx's stream and returns; records (HOST
+ * memory, ideally pinned) are valid after avd_synchronize.  Used by bench.py to
+ * time kernels with HIP events on the stream they run on. */
+int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                             int64_t row_stride, int64_t frame_stride,
+                             avd_frame_record* records);
+int avd_synchronize(avd_ctx* ctx);
+
+/* HIP-event timing of the work enqueued on ctx's stream between the two calls
+ * (milliseconds).  avd_timer_stop synchronizes the stream. */
+int avd_timer_start(avd_ctx* ctx);
+int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
+/* Per-stage device time (ms) of the LAST avd_analyze_frames* call when profiling
+ * was enabled with avd_set_profiling(ctx, 1): stage 0 = fused preprocess kernel,
+ * 1 = hash/hamming kernels, 2 = Farneback (pyramid .. flow), 3 = flow statistics. */
+int avd_set_profiling(avd_ctx* ctx, int enable);
+int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
+
+/* Test hook: copy an internal device buffer of the last call to host.
+ * name: "area" uint8[n][1024]; "pyr<L>" float[n][hL][wL]; "poly<L>" float[n][5][hL][wL];
+ * "flow<L>" float[n-1][2][hL][wL] (planar, after the last iteration at level L).
+ * Returns the number of bytes copied (>=0) or a negative status. */
+int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVD_H */

@@ -319,5 +319,4 @@ def analyze_sampled_frames(frames: np.ndarray, meta: dict, exact_numpy_var: bool
             timeline_ai = [0.5] * tlen
     else:
         timeline_ai = timeline_ai[:tlen]
-    return {"timeline": timeline_ai, "summary": summary, "timeline_ai": timeline_ai,
-            "_per_frame": {"textures": textures, "flow_means": flow_means, "flow_vars": flow_vars}}
+    return {"timeline": timeline_ai, "summary": summary, "timeline_ai": timeline_ai}
