@@ -49,6 +49,24 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).
+    Two HIP runtimes in one process cannot both own the GPU, and device pointers of torch
+    tensors are only meaningful to the runtime that allocated them -- so when torch is
+    installed, its runtime is loaded first and libavd_hip.so binds to it by SONAME."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return None
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -56,6 +74,7 @@ def load() -> C.CDLL:
     if not os.path.exists(SO_PATH):
         raise ImportError(f"{SO_PATH} is missing: build it with `make -C {CSRC}` "
                           "(there is no CPU fallback for the HIP path)")
+    _preload_hip_runtime()
     L = C.CDLL(SO_PATH)
     vp, u8p, f32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.avd_abi_version.restype = C.c_int
