@@ -192,29 +192,24 @@ __global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev,
 }
 
 // ---------------------------------------------------------------------------------------
-// FarnebackUpdateMatrices: per pixel, warp R1 by the current flow (bilinear), build the
-// 2x2 normal equations G, h.  R planes [frame][5][h][w]; M planes [pair][5][h][w].
+// FarnebackUpdateMatrices for one pixel: warp R1 by the current flow (bilinear), build the
+// five entries (G11, G12, G22, h1, h2) of the 2x2 normal equations.  R planes
+// [frame][5][h][w]; flow planes [pair][2][h][w].
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R, const float* __restrict__ flow,
-                                                        float* __restrict__ M, int w, int h, int npairs)
+__device__ __forceinline__ void normal_eq(const float* __restrict__ R0p, const float* __restrict__ R1p,
+                                          const float* __restrict__ flp, int x, int y, int w, int h,
+                                          float (&M)[5])
 {
-    const int64_t plane = (int64_t)w * h;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= npairs * plane) return;
-    const int x = (int)(gid % w);
-    const int y = (int)((gid / w) % h);
-    const int p = (int)(gid / plane);
-    const float* R0 = R + (int64_t)p * 5 * plane + y * w + x;
-    const float* R1 = R + (int64_t)(p + 1) * 5 * plane;
-    const float* fl = flow + (int64_t)p * 2 * plane + y * w + x;
-    const float dx = fl[0], dy = fl[plane];
+    const int plane = w * h;
+    const float* R0 = R0p + y * w + x;
+    const float dx = flp[y * w + x], dy = flp[plane + y * w + x];
     float fx = x + dx, fy = y + dy;
     const int x1 = floor_f(fx), y1 = floor_f(fy);
     float r2, r3, r4, r5, r6;
     fx -= x1; fy -= y1;
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float* q = R1 + y1 * w + x1;
+        const float* q = R1p + y1 * w + x1;
         r2 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
         r3 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
         r4 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
@@ -239,68 +234,224 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
                             (y < 5 ? border(y) : 1.f) * (y >= h - 5 ? border(h - y - 1) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
+// pointwise launch of normal_eq: M planes [pair][5][h][w]
+__global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R, const float* __restrict__ flow,
+                                                        float* __restrict__ M, int w, int h, int npairs)
+{
+    const int64_t plane = (int64_t)w * h;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npairs * plane) return;
+    const int x = (int)(gid % w);
+    const int y = (int)((gid / w) % h);
+    const int p = (int)(gid / plane);
+    float m[5];
+    normal_eq(R + (int64_t)p * 5 * plane, R + (int64_t)(p + 1) * 5 * plane, flow + (int64_t)p * 2 * plane, x, y, w, h, m);
     float* out = M + (int64_t)p * 5 * plane + y * w + x;
-    out[0] = r4 * r4 + r6 * r6;
-    out[plane] = (r4 + r5) * r6;
-    out[2 * plane] = r5 * r5 + r6 * r6;
-    out[3 * plane] = r4 * r2 + r6 * r3;
-    out[4 * plane] = r6 * r2 + r5 * r3;
+#pragma unroll
+    for (int c = 0; c < 5; c++) out[c * plane] = m[c];
 }
 
 // ---------------------------------------------------------------------------------------
 // FarnebackUpdateFlow_Blur, winsize 15 (m = 7).  cv2 keeps RUNNING box sums in double and
-// rounds at every slide, so the value at (y,x) depends on the whole column / row prefix:
-// the chains are reproduced literally, one lane per chain.
-//   k_blur_v : lane = (pair, channel, x), walks y;  VS[pair][c][y][x] (double)
-//   k_blur_h : lane = (pair, y), walks x with 5 running sums, solves the 2x2 system.
+// rounds at every slide, so the value at (y,x) depends on the whole column / row prefix; the
+// chains are reproduced literally, one lane per chain, in two kernels:
+//
+// k_vd  (lanes along x, sequential in y): vertical running sums vsum in double.  The
+//   horizontal pass only ever needs D(x) = vsum(x+7) - vsum(x-8), which is formed here with
+//   wave shuffles (a wave owns 48 output columns + 8/8 halo lanes, clamped at the edge = cv2's
+//   replicate border) and is the only thing written (+ columns 0..6 of vsum for the row init).
+//   D is stored in 64-row x 16-column tiles (8 KiB, one tile per channel), the unit k_hscan
+//   stages through LDS; inside a tile the 16 doubles of a row are XOR-swizzled by (row & 15)
+//   so that 64 lanes reading "their" row hit different LDS banks.  16 consecutive lanes still
+//   write one full 128-byte line.
+//
+// k_hscan (lanes along y, sequential in x): five horizontal running sums per row in one lane,
+//   2x2 solve per pixel.  Workgroup = 64 rows: wave 0 scans, wave 1 streams the next chunk's
+//   five tiles (40 KiB, perfectly coalesced) into the other LDS buffer.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_v(const float* __restrict__ M, double* __restrict__ VS,
-                                               int w, int h, int npairs)
+constexpr int kStripW = 48;          // output columns per wave in k_vd: 64 lanes - 8 - 8 halo
+
+__host__ __device__ constexpr int d16_xch(int w) { return (w + 15) / 16; }
+__host__ __device__ constexpr int d16_nyb(int h) { return (h + 63) / 64; }
+
+template <int W>
+__global__ __launch_bounds__(256) void k_vd(const float* __restrict__ M, double* __restrict__ D16,
+                                           double* __restrict__ VS0, int npairs)
 {
-    constexpr int m = 7;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (int64_t)npairs * 5 * w) return;
-    const int x = (int)(gid % w);
-    const int64_t pc = gid / w;
-    const float* src = M + pc * w * h + x;
-    double* dst = VS + pc * w * h + x;
-    double vs = (double)(src[0] * (float)(m + 2));
-    for (int y = 1; y < m; y++) vs += (double)src[min(y, h - 1) * w];
-    for (int y = 0; y < h; y++) {
-        const float a = src[min(y + m, h - 1) * w], b = src[max(y - m - 1, 0) * w];
-        vs += (double)(a - b);
-        dst[y * w] = vs;
+    constexpr int H = W, m = 7;
+    constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W), NYB = d16_nyb(H);
+    constexpr int64_t plane = (int64_t)W * H;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= npairs * NSTRIP) return;
+    const int lane = threadIdx.x & 63;
+    const int p = wid / NSTRIP, strip = wid - p * NSTRIP;
+    const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
+    const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
+    const float* Mp = M + (int64_t)p * 5 * plane + x;
+    const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
+    const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
+    double* Dt = D16 + ((int64_t)p * NYB * 5 * XCH + (x >> 4)) * 1024;       // tile column of this lane
+    double* V0 = VS0 + (int64_t)p * 5 * H * 8 + (lane - 8);
+    const int xs = x & 15;
+
+    // Rows y-8 .. y+7 of this column live in a register ring (slot = row & 15) so every M value
+    // is loaded once; loads run one 4-row sub-block ahead of the arithmetic (explicit prefetch:
+    // the compiler will not hoist loads across the predicated stores on its own).
+    float ring[16][5];
+    double vs[5];
+#pragma unroll
+    for (int r = 0; r < m; r++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) ring[r][c] = Mp[c * plane + r * W];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        vs[c] = (double)(ring[0][c] * (float)(m + 2));
+#pragma unroll
+        for (int r = 1; r < m; r++) vs[c] += (double)ring[r][c];
+    }
+    float pf[4][5];                                       // entering rows of the current sub-block
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) pf[j][c] = Mp[c * plane + min(j + m, H - 1) * W];
+
+    for (int yb = 0; yb < H; yb += 16) {
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+            const int y0 = yb + sb * 4;
+            if (y0 < H) {                                 // only false in the tail block of H = 40
+                float nx[4][5];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) nx[j][c] = Mp[c * plane + min(y0 + 4 + j + m, H - 1) * W];
+                double dv[4][5], hv[4][5];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int y = y0 + j;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        const float a = pf[j][c];         // row min(y+7, H-1)
+                        const float b = y >= m + 1 ? ring[(sb * 4 + j + 8) & 15][c] : ring[0][c];
+                        ring[(sb * 4 + j + m) & 15][c] = a;
+                        vs[c] += (double)(a - b);
+                        const double hi = __shfl(vs[c], lane + m, 64);
+                        const double lo = __shfl(vs[c], lane - m - 1, 64);
+                        dv[j][c] = hi - lo;
+                        hv[j][c] = vs[c];
+                    }
+                }
+                if (writer) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int y = y0 + j;
+                        const int64_t trow = ((int64_t)(y >> 6) * 5 * XCH) * 1024 + (y & 63) * 16 + (xs ^ (y & 15));
+#pragma unroll
+                        for (int c = 0; c < 5; c++) Dt[trow + (int64_t)c * XCH * 1024] = dv[j][c];
+                    }
+                }
+                if (head) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int c = 0; c < 5; c++) V0[(c * H + y0 + j) * 8] = hv[j][c];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) pf[j][c] = nx[j][c];
+            }
+        }
     }
 }
 
-__global__ __launch_bounds__(64) void k_blur_h(const double* __restrict__ VS, float* __restrict__ flow,
-                                              int w, int h, int npairs)
+template <int W>
+__global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, const double* __restrict__ VS0,
+                                              float* __restrict__ flow, int npairs)
 {
-    constexpr int m = 7;
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= npairs * h) return;
-    const int y = gid % h, p = gid / h;
-    const int64_t plane = (int64_t)w * h;
-    const double* v = VS + (int64_t)p * 5 * plane + y * w;
-    float* fl = flow + (int64_t)p * 2 * plane + y * w;
-    const double scale = 1. / (15 * 15);
-    double g[5];
+    constexpr int H = W, m = 7;
+    constexpr int XCH = d16_xch(W), NYB = d16_nyb(H);
+    constexpr int64_t plane = (int64_t)W * H;
+    extern __shared__ __align__(16) double lds[];       // [2][5][1024]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x / NYB, ybk = blockIdx.x - p * NYB;
+    const double* tiles = D16 + ((int64_t)p * NYB + ybk) * 5 * XCH * 1024;   // [c][xc][1024]
+
+    // loader (wave 1): tile image is copied verbatim, 16 B per lane, 8 KiB per channel
+    auto load_chunk = [&](int xc, int buf) {
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const double* vc = v + c * plane;
-        double s = vc[0] * (double)(m + 2);
-        for (int x = 1; x < m; x++) s += vc[min(x, w - 1)];
-        g[c] = s;
+        for (int half = 0; half < 2; half++) {
+            double2 st[5][4];
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    st[c][i] = *reinterpret_cast<const double2*>(tiles + ((int64_t)c * XCH + xc) * 1024 +
+                                                                  (half * 4 + i) * 128 + lane * 2);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    *reinterpret_cast<double2*>(lds + (buf * 5 + c) * 1024 + (half * 4 + i) * 128 + lane * 2) = st[c][i];
+        }
+    };
+
+    const int y = ybk * 64 + lane;
+    const bool live = y < H;
+    const int yc = min(y, H - 1);
+    double g[5] = {0, 0, 0, 0, 0};
+    float* fl = flow + (int64_t)p * 2 * plane + yc * W;
+    if (wave == 0) {
+        const double* v0 = VS0 + ((int64_t)p * 5 * H + yc) * 8;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double* vc = v0 + (int64_t)c * H * 8;
+            double s = vc[0] * (double)(m + 2);
+#pragma unroll
+            for (int k = 1; k < m; k++) s += vc[k];
+            g[c] = s;
+        }
+    } else {
+        load_chunk(0, 0);
     }
-    for (int x = 0; x < w; x++) {
-        const int xa = min(x + m, w - 1), xb = max(x - m - 1, 0);
+    __syncthreads();
+    const double scale = 1. / (15 * 15);
+    for (int xc = 0; xc < XCH; xc++) {
+        const int buf = xc & 1;
+        if (wave == 1) {
+            if (xc + 1 < XCH) load_chunk(xc + 1, buf ^ 1);
+        } else {
+            const double* t = lds + buf * 5 * 1024 + lane * 16;
+            const int sw = lane & 15;
 #pragma unroll
-        for (int c = 0; c < 5; c++) g[c] += v[c * plane + xa] - v[c * plane + xb];
-        const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
-        const double h1 = g[3] * scale, h2 = g[4] * scale;
-        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-        fl[x] = (float)((g11 * h2 - g12 * h1) * idet);
-        fl[plane + x] = (float)((g22 * h1 - g12 * h2) * idet);
+            for (int q4 = 0; q4 < 4; q4++) {
+                float ox[4], oy[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = q4 * 4 + jj;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) g[c] += t[c * 1024 + (j ^ sw)];
+                    const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+                    const double h1 = g[3] * scale, h2 = g[4] * scale;
+                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    ox[jj] = (float)((g11 * h2 - g12 * h1) * idet);
+                    oy[jj] = (float)((g22 * h1 - g12 * h2) * idet);
+                }
+                const int x = xc * 16 + q4 * 4;
+                if (live && x < W) {                    // W is a multiple of 8: a float4 is all-in or all-out
+                    *reinterpret_cast<float4*>(fl + x) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+                    *reinterpret_cast<float4*>(fl + plane + x) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -393,6 +544,28 @@ void pyramid_level(avd_ctx* ctx, const uint8_t* d_small, int n)
                        ws.d_poly[K]);
 }
 
+constexpr int kHscanLds = 2 * 5 * 1024 * (int)sizeof(double);      // 80 KiB, opt-in dynamic LDS
+
+// one FarnebackUpdateFlow_Blur iteration at level k: matrices from the current flow, box sums, solve
+template <int W>
+void blur_iteration(avd_ctx* ctx, int k, int np)
+{
+    Workspace& ws = ctx->ws;
+    constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute((const void*)k_hscan<W>, hipFuncAttributeMaxDynamicSharedMemorySize, kHscanLds);
+        lds_opt_in = true;
+    }
+    launch1d(k_update_matrices, (int64_t)np * W * W, 256, ctx->stream, (const float*)ws.d_poly[k],
+             (const float*)ws.d_flow[k], ws.d_M, W, W, np);
+    const int waves = np * NSTRIP;
+    hipLaunchKernelGGL(k_vd<W>, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, (const float*)ws.d_M, ws.d_vs,
+                       ws.d_vs0, np);
+    hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), kHscanLds, ctx->stream, (const double*)ws.d_vs,
+                       (const double*)ws.d_vs0, ws.d_flow[k], np);
+}
+
 }  // namespace
 
 // All pairs (f, f+1), f in [0, n-1), of n resident 320x320 frames.
@@ -413,14 +586,13 @@ int launch_farneback(avd_ctx* ctx, const uint8_t* d_small, int n)
         else
             launch1d(k_flow_up, (int64_t)np * 2 * plane, 256, ctx->stream, (const float*)ws.d_flow[k + 1],
                      w / 2, h / 2, ws.d_flow[k], w, h, np);
-        launch1d(k_update_matrices, np * plane, 256, ctx->stream, (const float*)ws.d_poly[k],
-                 (const float*)ws.d_flow[k], ws.d_M[0], w, h, np);
         for (int it = 0; it < 3; it++) {
-            launch1d(k_blur_v, (int64_t)np * 5 * w, 256, ctx->stream, (const float*)ws.d_M[0], ws.d_vs, w, h, np);
-            launch1d(k_blur_h, (int64_t)np * h, 64, ctx->stream, (const double*)ws.d_vs, ws.d_flow[k], w, h, np);
-            if (it < 2)
-                launch1d(k_update_matrices, np * plane, 256, ctx->stream, (const float*)ws.d_poly[k],
-                         (const float*)ws.d_flow[k], ws.d_M[0], w, h, np);
+            switch (k) {
+            case 3: blur_iteration<S / 8>(ctx, k, np); break;
+            case 2: blur_iteration<S / 4>(ctx, k, np); break;
+            case 1: blur_iteration<S / 2>(ctx, k, np); break;
+            default: blur_iteration<S>(ctx, k, np); break;
+            }
         }
     }
     HIP_TRY(ctx, hipGetLastError());
