@@ -163,20 +163,22 @@ __global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, in
 __global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev, int pw, int ph,
                                                 float* __restrict__ flow, int w, int h, int npairs)
 {
+    // destination is exactly 2x the source, so cv2's source coordinate (d+0.5)*0.5-0.5 = d/2 - 0.25
+    // is exact in float: s = floor, f in {0.75, 0.25}; horizontally the weights snap to the edge
+    // pixel (f = 0) when s falls outside [0, pw-1), vertically the rows are clipped, weights kept.
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (int64_t)npairs * 2 * w * h) return;
     const int dx = (int)(gid % w);
     const int dy = (int)((gid / w) % h);
     const int64_t pc = gid / ((int64_t)w * h);             // pair*2 + channel
     const float* src = prev + pc * pw * ph;
-    const double scale_x = 1. / ((double)w / pw), scale_y = 1. / ((double)h / ph);
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    float fx = dx * 0.5f - 0.25f;
     int sx = floor_f(fx);
     fx -= sx;
     if (sx < 0) { fx = 0; sx = 0; }
     bool edge = false;                                      // dx >= xmax: value copied, no weights
     if (sx + 1 >= pw) { edge = true; if (sx >= pw - 1) { fx = 0; sx = pw - 1; } }
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    float fy = dy * 0.5f - 0.25f;
     int sy = floor_f(fy);
     fy -= sy;
     const int y0 = clampi(sy, 0, ph - 1), y1 = clampi(sy + 1, 0, ph - 1);
@@ -267,18 +269,19 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
 //   horizontal pass only ever needs D(x) = vsum(x+7) - vsum(x-8), which is formed here with
 //   wave shuffles (a wave owns 48 output columns + 8/8 halo lanes, clamped at the edge = cv2's
 //   replicate border) and is the only thing written (+ columns 0..6 of vsum for the row init).
-//   D is stored in 64-row x 16-column tiles (8 KiB, one tile per channel), the unit k_hscan
-//   stages through LDS; inside a tile the 16 doubles of a row are XOR-swizzled by (row & 15)
-//   so that 64 lanes reading "their" row hit different LDS banks.  16 consecutive lanes still
-//   write one full 128-byte line.
+//   D is stored in 64-row x 8-column tiles (4 KiB, one tile per channel), the unit k_hscan
+//   stages through LDS; inside a tile the 8 doubles of a row are XOR-swizzled by (row & 7)
+//   so that lanes reading "their" row spread over the LDS banks.  8 consecutive lanes write
+//   one 64-byte half line.
 //
 // k_hscan (lanes along y, sequential in x): five horizontal running sums per row in one lane,
 //   2x2 solve per pixel.  Workgroup = 64 rows: wave 0 scans, wave 1 streams the next chunk's
-//   five tiles (40 KiB, perfectly coalesced) into the other LDS buffer.
+//   five tiles (20 KiB, perfectly coalesced) into the other LDS buffer; 40 KiB of LDS per
+//   workgroup keeps 4 workgroups on a CU, so a whole clip's rows are resident in one round.
 // ---------------------------------------------------------------------------------------
 constexpr int kStripW = 48;          // output columns per wave in k_vd: 64 lanes - 8 - 8 halo
 
-__host__ __device__ constexpr int d16_xch(int w) { return (w + 15) / 16; }
+__host__ __device__ constexpr int d16_xch(int w) { return (w + 7) / 8; }
 __host__ __device__ constexpr int d16_nyb(int h) { return (h + 63) / 64; }
 
 template <int W>
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(256) void k_vd(const float* __restrict__ M, double*
     const float* Mp = M + (int64_t)p * 5 * plane + x;
     const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
     const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-    double* Dt = D16 + ((int64_t)p * NYB * 5 * XCH + (x >> 4)) * 1024;       // tile column of this lane
+    double* Dt = D16 + ((int64_t)p * NYB * 5 * XCH + (x >> 3)) * 512;        // tile column of this lane
     double* V0 = VS0 + (int64_t)p * 5 * H * 8 + (lane - 8);
-    const int xs = x & 15;
+    const int xs = x & 7;
 
     // Rows y-8 .. y+7 of this column live in a register ring (slot = row & 15) so every M value
     // is loaded once; loads run one 4-row sub-block ahead of the arithmetic (explicit prefetch:
@@ -352,9 +355,9 @@ __global__ __launch_bounds__(256) void k_vd(const float* __restrict__ M, double*
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int y = y0 + j;
-                        const int64_t trow = ((int64_t)(y >> 6) * 5 * XCH) * 1024 + (y & 63) * 16 + (xs ^ (y & 15));
+                        const int64_t trow = ((int64_t)(y >> 6) * 5 * XCH) * 512 + (y & 63) * 8 + (xs ^ (y & 7));
 #pragma unroll
-                        for (int c = 0; c < 5; c++) Dt[trow + (int64_t)c * XCH * 1024] = dv[j][c];
+                        for (int c = 0; c < 5; c++) Dt[trow + (int64_t)c * XCH * 512] = dv[j][c];
                     }
                 }
                 if (head) {
@@ -379,28 +382,23 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     constexpr int H = W, m = 7;
     constexpr int XCH = d16_xch(W), NYB = d16_nyb(H);
     constexpr int64_t plane = (int64_t)W * H;
-    extern __shared__ __align__(16) double lds[];       // [2][5][1024]
+    __shared__ __align__(16) double lds[2][5][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x / NYB, ybk = blockIdx.x - p * NYB;
-    const double* tiles = D16 + ((int64_t)p * NYB + ybk) * 5 * XCH * 1024;   // [c][xc][1024]
+    const double* tiles = D16 + ((int64_t)p * NYB + ybk) * 5 * XCH * 512;   // [c][xc][512]
 
-    // loader (wave 1): tile image is copied verbatim, 16 B per lane, 8 KiB per channel
+    // loader (wave 1): the tile image is copied verbatim, 16 B per lane, 4 KiB per channel
     auto load_chunk = [&](int xc, int buf) {
+        double2 st[5][4];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            double2 st[5][4];
+        for (int c = 0; c < 5; c++)
 #pragma unroll
-            for (int c = 0; c < 5; c++)
+            for (int i = 0; i < 4; i++)
+                st[c][i] = *reinterpret_cast<const double2*>(tiles + ((int64_t)c * XCH + xc) * 512 + i * 128 + lane * 2);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    st[c][i] = *reinterpret_cast<const double2*>(tiles + ((int64_t)c * XCH + xc) * 1024 +
-                                                                  (half * 4 + i) * 128 + lane * 2);
+        for (int c = 0; c < 5; c++)
 #pragma unroll
-            for (int c = 0; c < 5; c++)
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    *reinterpret_cast<double2*>(lds + (buf * 5 + c) * 1024 + (half * 4 + i) * 128 + lane * 2) = st[c][i];
-        }
+            for (int i = 0; i < 4; i++) *reinterpret_cast<double2*>(&lds[buf][c][i * 128 + lane * 2]) = st[c][i];
     };
 
     const int y = ybk * 64 + lane;
@@ -428,27 +426,24 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
         if (wave == 1) {
             if (xc + 1 < XCH) load_chunk(xc + 1, buf ^ 1);
         } else {
-            const double* t = lds + buf * 5 * 1024 + lane * 16;
-            const int sw = lane & 15;
+            const int sw = lane & 7;
+            float ox[8], oy[8];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                float ox[4], oy[4];
+            for (int j = 0; j < 8; j++) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int j = q4 * 4 + jj;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) g[c] += t[c * 1024 + (j ^ sw)];
-                    const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
-                    const double h1 = g[3] * scale, h2 = g[4] * scale;
-                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                    ox[jj] = (float)((g11 * h2 - g12 * h1) * idet);
-                    oy[jj] = (float)((g22 * h1 - g12 * h2) * idet);
-                }
-                const int x = xc * 16 + q4 * 4;
-                if (live && x < W) {                    // W is a multiple of 8: a float4 is all-in or all-out
-                    *reinterpret_cast<float4*>(fl + x) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-                    *reinterpret_cast<float4*>(fl + plane + x) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-                }
+                for (int c = 0; c < 5; c++) g[c] += lds[buf][c][lane * 8 + (j ^ sw)];
+                const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+                const double h1 = g[3] * scale, h2 = g[4] * scale;
+                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                ox[j] = (float)((g11 * h2 - g12 * h1) * idet);
+                oy[j] = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+            if (live) {
+                float* o = fl + xc * 8;
+                *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(ox[4], ox[5], ox[6], ox[7]);
+                *reinterpret_cast<float4*>(o + plane) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+                *reinterpret_cast<float4*>(o + plane + 4) = make_float4(oy[4], oy[5], oy[6], oy[7]);
             }
         }
         __syncthreads();
@@ -461,67 +456,89 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
 // iterator buffers whose results are added sequentially.  One workgroup per pair.
 // ---------------------------------------------------------------------------------------
 constexpr int kChunk = 8192;
+constexpr int kNChunk = (AVD_NPIX + kChunk - 1) / kChunk;      // 13: twelve full buffers + one of 4096
 
-__global__ __launch_bounds__(1024) void k_flow_stats(const float* __restrict__ flow, float* __restrict__ stats,
-                                                    float* __restrict__ flow_il)
+// sequential combination of the per-buffer sums, as the ufunc reduction loop does
+__device__ __forceinline__ float chunk_total(const float* part)
+{
+    float t = part[0];
+#pragma unroll
+    for (int i = 1; i < kNChunk; i++) t += part[i];
+    return t;
+}
+
+// PASS 0: per-buffer pairwise sums of mag.  PASS 1: of (mag - mean)^2, mean = sum/N in float32.
+// grid (kNChunk, npairs); part[pair][pass][kNChunk]
+template <int PASS>
+__global__ __launch_bounds__(256) void k_stats_chunk(const float* __restrict__ flow, float* __restrict__ part)
 {
     __shared__ float buf[kChunk];
     __shared__ float leaf[kChunk / 16];              // 64 leaves x 8 accumulators
     __shared__ float node[64];
-    __shared__ float bc;
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const float* fxp = flow + (int64_t)p * 2 * AVD_NPIX;
+    const int p = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int base = ch * kChunk;
+    const int len = min(kChunk, AVD_NPIX - base);
+    const float* fxp = flow + (int64_t)p * 2 * AVD_NPIX + base;
     const float* fyp = fxp + AVD_NPIX;
-    float total = 0.f, mean32 = 0.f;
-    for (int pass = 0; pass < 2; pass++) {
-        total = 0.f;
-        for (int base = 0; base < AVD_NPIX; base += kChunk) {
-            const int len = min(kChunk, AVD_NPIX - base);
-            for (int i = tid; i < len; i += 1024) {
-                const float fx = fxp[base + i], fy = fyp[base + i];
-                const float a = fx * fx, b = fy * fy;
-                float mg = sqrtf(a + b);
-                if (pass == 0 && flow_il) {
-                    flow_il[((int64_t)p * AVD_NPIX + base + i) * 2] = fx;
-                    flow_il[((int64_t)p * AVD_NPIX + base + i) * 2 + 1] = fy;
-                }
-                if (pass == 1) { const float d = mg - mean32; mg = d * d; }
-                buf[i] = mg;
-            }
-            __syncthreads();
-            const int nleaf = len >> 7;
-            for (int it = tid; it < nleaf * 8; it += 1024) {
-                const float* q = buf + (it >> 3) * 128 + (it & 7);
-                float r = q[0];
-#pragma unroll
-                for (int k = 1; k < 16; k++) r += q[8 * k];
-                leaf[it] = r;
-            }
-            __syncthreads();
-            if (tid < nleaf) {
-                const float* r = leaf + tid * 8;
-                node[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            }
-            __syncthreads();
-            // balanced pairwise tree over the leaves (nleaf is a power of two: 64 or 32)
-            for (int stride = 1; stride < nleaf; stride <<= 1) {
-                if (tid < nleaf && (tid % (2 * stride)) == 0) node[tid] = node[tid] + node[tid + stride];
-                __syncthreads();
-            }
-            if (tid == 0) total = base == 0 ? node[0] : total + node[0];
-            __syncthreads();
+    float mean32 = 0.f;
+    if (PASS == 1) mean32 = chunk_total(part + (int64_t)p * 2 * kNChunk) / (float)AVD_NPIX;   // _var: f32 true_divide
+    for (int i = tid * 4; i < len; i += 1024) {
+        const float4 fx = *reinterpret_cast<const float4*>(fxp + i), fy = *reinterpret_cast<const float4*>(fyp + i);
+        float4 mg;
+        mg.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
+        mg.y = sqrtf(fx.y * fx.y + fy.y * fy.y);
+        mg.z = sqrtf(fx.z * fx.z + fy.z * fy.z);
+        mg.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
+        if (PASS == 1) {
+            float d;
+            d = mg.x - mean32; mg.x = d * d;
+            d = mg.y - mean32; mg.y = d * d;
+            d = mg.z - mean32; mg.z = d * d;
+            d = mg.w - mean32; mg.w = d * d;
         }
-        if (pass == 0) {
-            if (tid == 0) {
-                bc = total / (float)AVD_NPIX;                       // _var: float32 array true_divide
-                stats[2 * p] = (float)((double)total / (double)AVD_NPIX);   // _mean
-            }
-            __syncthreads();
-            mean32 = bc;
-        } else if (tid == 0) {
-            stats[2 * p + 1] = (float)((double)total / (double)AVD_NPIX);
-        }
+        *reinterpret_cast<float4*>(buf + i) = mg;
     }
+    __syncthreads();
+    const int nleaf = len >> 7;                       // 64 or 32: a power of two
+    for (int it = tid; it < nleaf * 8; it += 256) {
+        const float* q = buf + (it >> 3) * 128 + (it & 7);
+        float r = q[0];
+#pragma unroll
+        for (int k = 1; k < 16; k++) r += q[8 * k];
+        leaf[it] = r;
+    }
+    __syncthreads();
+    if (tid < nleaf) {
+        const float* r = leaf + tid * 8;
+        node[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+    __syncthreads();
+    for (int stride = 1; stride < nleaf; stride <<= 1) {     // balanced pairwise tree over the leaves
+        if (tid < nleaf && (tid % (2 * stride)) == 0) node[tid] = node[tid] + node[tid + stride];
+        __syncthreads();
+    }
+    if (tid == 0) part[((int64_t)p * 2 + PASS) * kNChunk + ch] = node[0];
+}
+
+// stats[pair] = { f32(f64(sum)/N), f32(f64(sumsq)/N) }   (_mean / _var final scalar divides)
+__global__ void k_stats_final(const float* __restrict__ part, float* __restrict__ stats, int npairs)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const float s = chunk_total(part + (int64_t)p * 2 * kNChunk);
+    const float q = chunk_total(part + ((int64_t)p * 2 + 1) * kNChunk);
+    stats[2 * p] = (float)((double)s / (double)AVD_NPIX);
+    stats[2 * p + 1] = (float)((double)q / (double)AVD_NPIX);
+}
+
+// planar flow [pair][2][N] -> cv2's interleaved [pair][N][2] (only when the caller asks for the flow)
+__global__ void k_flow_interleave(const float* __restrict__ flow, float* __restrict__ out, int64_t total)
+{
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int64_t p = gid / AVD_NPIX, i = gid - p * AVD_NPIX;
+    out[gid * 2] = flow[p * 2 * AVD_NPIX + i];
+    out[gid * 2 + 1] = flow[(p * 2 + 1) * AVD_NPIX + i];
 }
 
 template <typename... A>
@@ -544,25 +561,18 @@ void pyramid_level(avd_ctx* ctx, const uint8_t* d_small, int n)
                        ws.d_poly[K]);
 }
 
-constexpr int kHscanLds = 2 * 5 * 1024 * (int)sizeof(double);      // 80 KiB, opt-in dynamic LDS
-
 // one FarnebackUpdateFlow_Blur iteration at level k: matrices from the current flow, box sums, solve
 template <int W>
 void blur_iteration(avd_ctx* ctx, int k, int np)
 {
     Workspace& ws = ctx->ws;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute((const void*)k_hscan<W>, hipFuncAttributeMaxDynamicSharedMemorySize, kHscanLds);
-        lds_opt_in = true;
-    }
     launch1d(k_update_matrices, (int64_t)np * W * W, 256, ctx->stream, (const float*)ws.d_poly[k],
              (const float*)ws.d_flow[k], ws.d_M, W, W, np);
     const int waves = np * NSTRIP;
     hipLaunchKernelGGL(k_vd<W>, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, (const float*)ws.d_M, ws.d_vs,
                        ws.d_vs0, np);
-    hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), kHscanLds, ctx->stream, (const double*)ws.d_vs,
+    hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, ctx->stream, (const double*)ws.d_vs,
                        (const double*)ws.d_vs0, ws.d_flow[k], np);
 }
 
@@ -603,8 +613,14 @@ int launch_flow_stats(avd_ctx* ctx, int n)
 {
     if (n < 2) return 0;
     Workspace& ws = ctx->ws;
-    hipLaunchKernelGGL(k_flow_stats, dim3(n - 1), dim3(1024), 0, ctx->stream, (const float*)ws.d_flow[0],
-                       ws.d_stats, ws.d_flow_il);
+    const int np = n - 1;
+    const float* fl = ws.d_flow[0];
+    hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, ctx->stream, fl, ws.d_part);
+    hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, ctx->stream, fl, ws.d_part);
+    hipLaunchKernelGGL(k_stats_final, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, (const float*)ws.d_part,
+                       ws.d_stats, np);
+    if (ws.d_flow_il)
+        launch1d(k_flow_interleave, (int64_t)np * AVD_NPIX, 256, ctx->stream, fl, ws.d_flow_il, (int64_t)np * AVD_NPIX);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -93,6 +93,7 @@ struct Workspace {
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
     float* d_stats = nullptr;             // [n-1][2] mean, var
+    float* d_part = nullptr;              // [n-1][2][13] per-buffer partial sums (numpy reduction order)
     avd_frame_record* d_rec = nullptr;    // [n]
     avd_frame_record* h_rec = nullptr;    // pinned [n]
 };
