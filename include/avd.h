@@ -105,9 +105,10 @@ int avd_synchronize(avd_ctx* ctx);
  * (milliseconds).  avd_timer_stop synchronizes the stream. */
 int avd_timer_start(avd_ctx* ctx);
 int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
-/* Per-stage device time (ms) of the LAST avd_analyze_frames* call when profiling
- * was enabled with avd_set_profiling(ctx, 1): stage 0 = fused preprocess kernel,
- * 1 = hash/hamming kernels, 2 = Farneback (pyramid .. flow), 3 = flow statistics. */
+/* Per-stage device time (ms, HIP events on ctx's stream) of the LAST avd_analyze_frames*
+ * call when profiling was enabled with avd_set_profiling(ctx, 1): stage 0 = fused
+ * preprocess kernel (+ the 2 KB moment memset), 1 = hash / Hamming / record kernels,
+ * 2 = Farneback (pyramid .. flow) + flow statistics, 3 = records copy-out. */
 int avd_set_profiling(avd_ctx* ctx, int enable);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 
