@@ -1,6 +1,7 @@
 // avd_capi.hip -- C-ABI of libavd_hip.so (include/avd.h): context, workspace, entry points.
 // Host C++; every kernel lives in avd_preprocess.hip / avd_farneback.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include "avd_internal.h"
@@ -28,7 +29,9 @@ int rows_per_band_for(int w)
     // LDS tile = (rows+2) * pitch bytes, kept under 48 KiB so that >= 3 workgroups fit a CU
     const int pitch = ((w + 32 + 15) / 16) * 16;
     int r = (48 * 1024) / pitch - 2;
-    r = std::min(r, 16);
+    int cap = 16;
+    if (const char* e = std::getenv("AVD_ROWS_PER_BAND")) cap = std::max(1, std::atoi(e));   // tuning knob
+    r = std::min(r, cap);
     return std::max(r, 1);
 }
 
@@ -47,7 +50,7 @@ struct TableBlob {
 void free_ws(Workspace& ws)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap);
+    F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap); F(ws.d_lap_part);
     F(ws.d_tables);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
     F(ws.d_tmp); F(ws.d_M); F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
@@ -109,6 +112,11 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
         P.ax_begin = (const int*)(dt + o_axb); P.ax_count = (const int*)(dt + o_axc);
         P.ax_first = (const float*)(dt + o_axf); P.ax_mid = (const float*)(dt + o_axm); P.ax_last = (const float*)(dt + o_axl);
         P.area_fast = at.fast;
+        P.area_x_uniform4 = 1;
+        for (int d = 0; d < AVD_HASH; d++)
+            if ((at.x.begin[d] & 3) || (at.x.count[d] & 3) || at.x.count[d] < 4 || at.x.w_first[d] != at.x.w_mid[d] ||
+                at.x.w_last[d] != at.x.w_mid[d])
+                P.area_x_uniform4 = 0;
         P.h = h; P.w = w; P.rows_per_band = R; P.nbands = nbands;
         P.pitch = ((w + 32 + 15) / 16) * 16;
         HashParams& H = ws.hsh;
@@ -127,6 +135,7 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
         if (int e = dev_alloc(ctx, ws.d_hash, (size_t)cap * 1024)) return e;
         if (int e = dev_alloc(ctx, ws.d_ham, (size_t)cap)) return e;
         if (int e = dev_alloc(ctx, ws.d_lap, (size_t)cap * 2)) return e;
+        if (int e = dev_alloc(ctx, ws.d_lap_part, (size_t)cap * ws.pre.nbands * 8 * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_rec, (size_t)cap)) return e;
         if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
         HIP_TRY(ctx, hipHostMalloc((void**)&ws.h_rec, sizeof(avd_frame_record) * cap, hipHostMallocDefault));
@@ -258,6 +267,9 @@ int avd_create(int device_id, avd_ctx** out)
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
     if (ok) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = prop.multiProcessorCount;
         build_fb_consts(ctx->fbc);
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
              hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;

@@ -58,8 +58,10 @@ struct PreParams {
     const int *ax_begin, *ax_count;
     const float *ax_first, *ax_mid, *ax_last;
     int area_fast;
+    int area_x_uniform4;               // every x cell: begin%4==0, count%4==0, single weight
     int h, w, rows_per_band, nbands, pitch;
     int64_t row_stride, frame_stride;
+    int dbg_skip;                      // timing experiments only (AVD_DBG_SKIP): 1 lap, 2 area, 4 linear, 8 gray math, 16 loads
 };
 
 struct HashParams {
@@ -80,6 +82,8 @@ struct Workspace {
     uint8_t* d_hash = nullptr;        // [n][1024]
     int* d_ham = nullptr;             // [n]
     unsigned long long* d_lap = nullptr;   // [n][2]
+    long long* d_lap_part = nullptr;       // [n][nbands][8 waves][2] per-wave partial moments
+    int lap_waves = 4;
     void* d_tables = nullptr; size_t tables_bytes = 0;
     PreParams pre{};
     HashParams hsh{};
@@ -100,6 +104,7 @@ struct Workspace {
 
 struct avd_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t stage_ev[5] = {};

@@ -14,12 +14,15 @@
 // fixed-point gray conversion into an LDS tile of uint8; phases 2-4 read only LDS.
 // Consecutive bands of a frame are placed on the same XCD (blockIdx remap) so the
 // halo rows hit that XCD's L2.
+#include <algorithm>
+#include <cstdlib>
 #include "avd_internal.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kPad = 16;     // bytes of padding left of pixel 0 in every LDS tile row
+constexpr int kLapSlots = 8; // per-band slots for per-wave Laplacian partial moments (<= 8 waves/workgroup)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -73,15 +76,190 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
     return lid;      // may be >= total (idle tail block)
 }
 
+__device__ __forceinline__ int reflect_once(int p, int len)      // valid for -len < p < 2*len-1
+{
+    p = p < 0 ? -p : p;
+    return p >= len ? 2 * len - 2 - p : p;
+}
+
+// 16 BGR pixels (three 16-byte words) -> 16 gray bytes
+__device__ __forceinline__ uint4 gray16(const uint4& a, const uint4& b, const uint4& d)
+{
+    uint4 g;
+    g.x = gray4(a.x, a.y, a.z);
+    g.y = gray4(a.w, b.x, b.y);
+    g.z = gray4(b.z, b.w, d.x);
+    g.w = gray4(d.y, d.z, d.w);
+    return g;
+}
+
+struct Moments { long long s, q; };
+
+// Phases 2-4 of a band whose gray rows [r0-1, r0+rows] (incl. column halo) sit in `tile`:
+// exact Laplacian moments, INTER_AREA horizontal partials, INTER_LINEAR 320x320 rows.
+// NT = workgroup size.  LTAB: the resampling tables were copied to LDS (layout LdsTabs) so that the
+// compute phases issue no global LOADS (the pipelined kernel keeps the next band's loads in flight
+// here, and vmcnt retires in order).
+struct LdsTabs {
+    int lx0[AVD_SMALL], lx1[AVD_SMALL], ly0[AVD_SMALL], ly1[AVD_SMALL];
+    short la0[AVD_SMALL], la1[AVD_SMALL], lb0[AVD_SMALL], lb1[AVD_SMALL];
+    int ax_begin[AVD_HASH], ax_count[AVD_HASH];
+    float ax_first[AVD_HASH], ax_mid[AVD_HASH], ax_last[AVD_HASH];
+    int band_dy[512];
+};
+
+template <int NT, bool LTAB>
+__device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTabs* lt, const PreParams& P, int f,
+                                               int band, int r0, int rows, int tid, uint8_t* __restrict__ small,
+                                               float* __restrict__ rowbuf)
+{
+    constexpr int kThreads = NT;
+    const int w = P.w, h = P.h, pitch = P.pitch;
+    // ---- Laplacian moments, exact, from row-pair products -----------------------------------
+    // lap(t,x) = T(t-1,x) + T(t+1,x) + T(t,x-1) + T(t,x+1) - 4 T(t,x) on the haloed tile T
+    // (tile row t = 1..rows are the band's rows).  Expanding sum lap^2 gives 15 sums of byte
+    // products per band row; products that involve the same two tile rows are shared between
+    // neighbouring band rows, so it is enough to form, when tile row n "enters" a lane's column
+    // walk, seven v_dot4_u32_u8 with the rows above it:
+    //   A(n)=C.C  HR(n)=C.R  H2(n)=L.R  V1(n-1)=C'.C  V2(n-2)=C''.C  Dp(n-1)=C'.R  Dm(n-1)=C'.L
+    // (C = 4 gray bytes of row n, L/R = the same shifted by -1/+1 pixel, ' = previous row).
+    // Row n contributes with weights that depend only on whether n-1, n, n+1 are band rows:
+    //   A: [n+1 in B] + [n-1 in B] + 18 [n in B]      V1, Dp, Dm: (-8|+2|+2) ([n in B] + [n-1 in B])
+    //   HR: -16 [n in B]   H2: +2 [n in B]   V2: +2 [n-1 in B]    row sum: [n+1 in B]+[n-1 in B]-2[n in B]
+    // Interior rows (2 <= n <= rows-1) have constant weights (20,-16,2,-16,2,4,4; row sum 0) and
+    // accumulate in place; the <= 4 boundary rows use a multiply-add per product.  What the
+    // column shifts miss at x = 0 / w-1 is added per band row as exact scalar edge terms.
+    long long s_acc = 0, q_acc = 0;
+    if (!(P.dbg_skip & 1)) {
+        const int quads = (w + 3) >> 2;
+        const int trows = rows + 2;
+        const unsigned ones = 0x01010101u;
+        unsigned iA = 0, iHR = 0, iH2 = 0, iV1 = 0, iV2 = 0, iDp = 0, iDm = 0;   // interior rows
+        int bq = 0, bs = 0;                                                        // boundary rows, weighted
+        for (int qx = tid; qx < quads; qx += kThreads) {
+            const uint8_t* col = tile + kPad + qx * 4;
+            unsigned mk = 0xFFFFFFFFu;
+            if (w & 3) {                                   // ragged last quad: drop pixels >= w
+                const int valid = w - qx * 4;
+                if (valid < 4) mk = (1u << (8 * valid)) - 1u;
+            }
+            unsigned C1 = 0, C2 = 0;                       // rows n-1, n-2
+            for (int nrow = 0; nrow < trows; nrow++) {
+                const uint8_t* cp = col + nrow * pitch;
+                const unsigned Cw = *reinterpret_cast<const unsigned*>(cp);
+                const unsigned Lw = *reinterpret_cast<const unsigned*>(cp - 4);
+                const unsigned Rw = *reinterpret_cast<const unsigned*>(cp + 4);
+                const unsigned C = Cw & mk;
+                const unsigned L = __builtin_amdgcn_alignbyte(Cw, Lw, 3) & mk;
+                const unsigned R = __builtin_amdgcn_alignbyte(Rw, Cw, 1) & mk;
+                if (nrow >= 2 && nrow <= rows - 1) {
+                    iA = __builtin_amdgcn_udot4(C, C, iA, false);
+                    iHR = __builtin_amdgcn_udot4(C, R, iHR, false);
+                    iH2 = __builtin_amdgcn_udot4(L, R, iH2, false);
+                    iV1 = __builtin_amdgcn_udot4(C1, C, iV1, false);
+                    iV2 = __builtin_amdgcn_udot4(C2, C, iV2, false);
+                    iDp = __builtin_amdgcn_udot4(C1, R, iDp, false);
+                    iDm = __builtin_amdgcn_udot4(C1, L, iDm, false);
+                } else {
+                    const int in0 = nrow >= 1 && nrow <= rows;          // n   in B
+                    const int inm = nrow >= 2 && nrow <= rows + 1;      // n-1 in B
+                    const int inp = nrow + 1 <= rows;                   // n+1 in B  (n >= 0 always)
+                    const int wA = inp + inm + 18 * in0, wP = in0 + inm;
+                    bq += wA * (int)__builtin_amdgcn_udot4(C, C, 0u, false);
+                    bq -= 16 * in0 * (int)__builtin_amdgcn_udot4(C, R, 0u, false);
+                    bq += 2 * in0 * (int)__builtin_amdgcn_udot4(L, R, 0u, false);
+                    bq -= 8 * wP * (int)__builtin_amdgcn_udot4(C1, C, 0u, false);
+                    bq += 2 * inm * (int)__builtin_amdgcn_udot4(C2, C, 0u, false);
+                    bq += 2 * wP * (int)__builtin_amdgcn_udot4(C1, R, 0u, false);
+                    bq += 2 * wP * (int)__builtin_amdgcn_udot4(C1, L, 0u, false);
+                    bs += (inp + inm - 2 * in0) * (int)__builtin_amdgcn_udot4(C, ones, 0u, false);
+                }
+                C2 = C1; C1 = C;
+            }
+        }
+        q_acc = 20ll * iA - 16ll * iHR + 2ll * iH2 - 16ll * iV1 + 2ll * iV2 + 4ll * iDp + 4ll * iDm + bq;
+        s_acc = bs;
+        // edge terms of band row t (tile row t = tid + 1): the l/r shifted sums run over x-1 / x+1
+        if (tid < rows) {
+            const uint8_t* r = tile + (tid + 1) * pitch + kPad;
+            const uint8_t* dn = r + pitch;
+            const int a = r[-1], b0 = r[0], e = r[w - 1], z = r[w];      // T(t,-1), T(t,0), T(t,w-1), T(t,w)
+            const int da = dn[-1], db = dn[0], de = dn[w - 1], dz = dn[w];
+            s_acc += a - e - b0 + z;
+            q_acc += (a * a - e * e) + (z * z - b0 * b0)                // l^2 + r^2
+                     - 8 * (a * b0 - e * z)                            // m*l
+                     + 2 * (a * db - e * dz)                           // d*l
+                     + 2 * (z * de - b0 * da);                         // d*r
+        }
+    }
+
+    // ---- INTER_AREA horizontal partials, one float chain per (row, cell), cv2's order ----
+    if (!(P.dbg_skip & 2)) {
+        float* out = rowbuf + ((int64_t)f * h + r0) * AVD_HASH;
+        for (int it = tid; it < rows * AVD_HASH; it += kThreads) {
+            const int r = it >> 5, dx = it & 31;
+            const uint8_t* src = tile + (r + 1) * pitch + kPad + (LTAB ? lt->ax_begin[dx] : P.ax_begin[dx]);
+            const int cnt = LTAB ? lt->ax_count[dx] : P.ax_count[dx];
+            if (P.area_fast) {
+                int acc = 0;
+                for (int k = 0; k < cnt; k++) acc += src[k];
+                out[it] = __int_as_float(acc);
+            } else if (P.area_x_uniform4) {
+                // every cell starts on a 4-byte boundary, spans a multiple of 4 pixels, one weight
+                const float wgt = LTAB ? lt->ax_mid[dx] : P.ax_mid[dx];
+                const unsigned* s4 = reinterpret_cast<const unsigned*>(src);
+                float acc = 0.f;
+                for (int k = 0; k < (cnt >> 2); k++) {
+                    const unsigned v = s4[k];
+                    acc = __fadd_rn(acc, __fmul_rn((float)(v & 0xFF), wgt));
+                    acc = __fadd_rn(acc, __fmul_rn((float)((v >> 8) & 0xFF), wgt));
+                    acc = __fadd_rn(acc, __fmul_rn((float)((v >> 16) & 0xFF), wgt));
+                    acc = __fadd_rn(acc, __fmul_rn((float)(v >> 24), wgt));
+                }
+                out[it] = acc;
+            } else {
+                const float wf = LTAB ? lt->ax_first[dx] : P.ax_first[dx], wm = LTAB ? lt->ax_mid[dx] : P.ax_mid[dx],
+                            wl = LTAB ? lt->ax_last[dx] : P.ax_last[dx];
+                float acc = 0.f;
+                for (int k = 0; k < cnt; k++) {
+                    const float wgt = k == 0 ? wf : (k == cnt - 1 ? wl : wm);
+                    acc = __fadd_rn(acc, __fmul_rn((float)src[k], wgt));
+                }
+                out[it] = acc;
+            }
+        }
+    }
+
+    // ---- INTER_LINEAR 320x320 rows whose upper source row lies in this band ----------------
+    if (!(P.dbg_skip & 4)) {
+        const int d0 = LTAB ? lt->band_dy[band] : P.band_dy[band], d1 = LTAB ? lt->band_dy[band + 1] : P.band_dy[band + 1];
+        uint8_t* dst = small + (int64_t)f * AVD_NPIX;
+        for (int it = tid; it < (d1 - d0) * AVD_SMALL; it += kThreads) {
+            const int dy = d0 + it / AVD_SMALL, dx = it % AVD_SMALL;
+            const uint8_t* ra = tile + ((LTAB ? lt->ly0[dy] : P.ly0[dy]) - r0 + 1) * pitch + kPad;
+            const uint8_t* rb = tile + ((LTAB ? lt->ly1[dy] : P.ly1[dy]) - r0 + 1) * pitch + kPad;
+            const int x0 = LTAB ? lt->lx0[dx] : P.lx0[dx], x1 = LTAB ? lt->lx1[dx] : P.lx1[dx];
+            const int a0 = LTAB ? lt->la0[dx] : P.la0[dx], a1 = LTAB ? lt->la1[dx] : P.la1[dx];
+            const int b0 = LTAB ? lt->lb0[dy] : P.lb0[dy], b1 = LTAB ? lt->lb1[dy] : P.lb1[dy];
+            const int ha = ra[x0] * a0 + ra[x1] * a1;
+            const int hb = rb[x0] * a0 + rb[x1] * a1;
+            dst[dy * AVD_SMALL + dx] = (uint8_t)((((b0 * (ha >> 4)) >> 16) + ((b1 * (hb >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+    Moments m;
+    m.s = s_acc;
+    m.q = q_acc;
+    return m;
+}
+
+// Generic kernel: one workgroup per band, any geometry / alignment (scalar loads if needed).
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_preprocess(const uint8_t* __restrict__ bgr, int n,
                                                         PreParams P, uint8_t* __restrict__ small,
                                                         float* __restrict__ rowbuf,
-                                                        unsigned long long* __restrict__ lap_acc)
+                                                        long long* __restrict__ lap_part)
 {
     extern __shared__ __align__(16) uint8_t tile[];
-    __shared__ long long red[2][kThreads / 64];
-
     const int total = n * P.nbands;
     const int lid = xcd_remap(blockIdx.x, total);
     if (lid >= total) return;
@@ -92,27 +270,19 @@ __global__ __launch_bounds__(kThreads) void k_preprocess(const uint8_t* __restri
     const int rows = min(P.rows_per_band, h - r0);
     const int tid = threadIdx.x;
     const uint8_t* frame = bgr + (int64_t)f * P.frame_stride;
-
-    // ---- phase 1: BGR -> gray tile rows [r0-1, r0+rows] (tile row 0 = r0-1) ----------
-    const int trows = rows + 2;
+    const int trows = rows + 2;                            // tile row 0 = image row r0-1
     if (VEC) {
-        const int chunks = w >> 4;                       // 16 pixels = 48 bytes per chunk
+        const int chunks = w >> 4;
         for (int it = tid; it < trows * chunks; it += kThreads) {
             const int tr = it / chunks, c = it - tr * chunks;
-            const int y = reflect101(r0 - 1 + tr, h);
+            const int y = reflect_once(r0 - 1 + tr, h);
             const uint4* src = reinterpret_cast<const uint4*>(frame + (int64_t)y * P.row_stride + c * 48);
-            const uint4 a = src[0], b = src[1], d = src[2];
-            uint4 g;
-            g.x = gray4(a.x, a.y, a.z);
-            g.y = gray4(a.w, b.x, b.y);
-            g.z = gray4(b.z, b.w, d.x);
-            g.w = gray4(d.y, d.z, d.w);
-            *reinterpret_cast<uint4*>(tile + tr * pitch + kPad + c * 16) = g;
+            *reinterpret_cast<uint4*>(tile + tr * pitch + kPad + c * 16) = gray16(src[0], src[1], src[2]);
         }
     } else {
         for (int it = tid; it < trows * w; it += kThreads) {
             const int tr = it / w, x = it - tr * w;
-            const int y = reflect101(r0 - 1 + tr, h);
+            const int y = reflect_once(r0 - 1 + tr, h);
             tile[tr * pitch + kPad + x] = (uint8_t)gray1(frame + (int64_t)y * P.row_stride + x * 3);
         }
     }
@@ -124,100 +294,183 @@ __global__ __launch_bounds__(kThreads) void k_preprocess(const uint8_t* __restri
         row[w] = row[reflect101(w, w)];
     }
     __syncthreads();
+    const Moments m = band_phases<kThreads, false>(tile, nullptr, P, f, band, r0, rows, tid, small, rowbuf);
+    // per-wave partial moments, summed per frame in k_hash (atomics on the 16 B/frame accumulators
+    // serialise in L2: 65 k same-line atomics cost ~50 us per launch)
+    const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
+    if ((tid & 63) == 0) {
+        long long* slot = lap_part + ((int64_t)lid * kLapSlots + (tid >> 6)) * 2;
+        slot[0] = s64; slot[1] = q64;
+    }
+}
 
-    // ---- phase 2: Laplacian moments over rows [r0, r0+rows) ----------------------------
-    // 4 pixels per step as two packed 16-bit lanes (even / odd bytes); lap+1020 stays positive.
-    int s_acc = 0;
-    unsigned q_acc = 0;
-    {
-        const int quads = (w + 3) >> 2;
-        for (int it = tid; it < rows * quads; it += kThreads) {
-            const int r = it / quads, qx = it - r * quads;
-            const uint8_t* c_row = tile + (r + 1) * pitch + kPad + qx * 4;
-            const unsigned C = *reinterpret_cast<const unsigned*>(c_row);
-            const unsigned Lw = *reinterpret_cast<const unsigned*>(c_row - 4);
-            const unsigned Rw = *reinterpret_cast<const unsigned*>(c_row + 4);
-            const unsigned U = *reinterpret_cast<const unsigned*>(c_row - pitch);
-            const unsigned D = *reinterpret_cast<const unsigned*>(c_row + pitch);
-            const unsigned L = __builtin_amdgcn_alignbyte(C, Lw, 3);
-            const unsigned R = __builtin_amdgcn_alignbyte(Rw, C, 1);
-            const unsigned NC = ~C;                       // 255 - c per byte
-            const unsigned m = 0x00FF00FFu;
-            // even bytes (pixels 0,2) and odd bytes (pixels 1,3): u+d+l+r + 4*(255-c) = lap + 1020
-            unsigned te = (U & m) + (D & m) + (L & m) + (R & m) + ((NC & m) << 2);
-            unsigned to = ((U >> 8) & m) + ((D >> 8) & m) + ((L >> 8) & m) + ((R >> 8) & m) + (((NC >> 8) & m) << 2);
-            int l0 = (int)(te & 0xFFFF) - 1020, l2 = (int)(te >> 16) - 1020;
-            int l1 = (int)(to & 0xFFFF) - 1020, l3 = (int)(to >> 16) - 1020;
-            const int valid = w - qx * 4;                 // >= 4 except in a ragged last quad
-            if (valid < 4) {
-                if (valid < 2) l1 = 0;
-                if (valid < 3) l2 = 0;
-                l3 = 0;
-            }
-            s_acc += l0 + l1 + l2 + l3;
-            q_acc += (unsigned)(l0 * l0) + (unsigned)(l1 * l1) + (unsigned)(l2 * l2) + (unsigned)(l3 * l3);
+// Aligned fast path (w % 16 == 0, <= 4096 px): one workgroup per band like the generic kernel, but
+// every lane owns one 16-pixel column chunk and issues ALL its NI row loads (3 x 16 B each) before
+// the first conversion, so a workgroup has its whole band in flight at once; conversions start as
+// the words arrive (vmcnt counts down in issue order).  The lanes that convert the first / last
+// chunk also write the reflected halo bytes, which saves a barrier.
+template <int NI>
+__global__ __launch_bounds__(kThreads, 4) void k_preprocess_vec(const uint8_t* __restrict__ bgr, int n,
+                                                               PreParams P, uint8_t* __restrict__ small,
+                                                               float* __restrict__ rowbuf,
+                                                               long long* __restrict__ lap_part)
+{
+    extern __shared__ __align__(16) uint8_t tile[];
+    const int total = n * P.nbands;
+    const int lid = xcd_remap(blockIdx.x, total);
+    if (lid >= total) return;
+    const int f = lid / P.nbands, band = lid - f * P.nbands;
+    const int h = P.h, w = P.w, pitch = P.pitch;
+    const int r0 = band * P.rows_per_band;
+    const int rows = min(P.rows_per_band, h - r0);
+    const int trows = rows + 2;
+    const int tid = threadIdx.x;
+    const int chunks = w >> 4;
+    const int rpp = kThreads / chunks;                     // tile rows covered per pass of the workgroup
+    const int rsub = tid / chunks, c = tid - rsub * chunks;
+    if (rsub < rpp) {
+        const uint8_t* col = bgr + (int64_t)f * P.frame_stride + c * 48;
+        uint4 q[NI][3];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int t = min(rsub + k * rpp, trows - 1);  // surplus items re-read the last row (same bytes)
+            const int y = reflect_once(r0 - 1 + t, h);
+            const uint4* src = reinterpret_cast<const uint4*>(col + (int64_t)y * P.row_stride);
+            if (P.dbg_skip & 16) { q[k][0] = q[k][1] = q[k][2] = make_uint4(t, y, k, c); continue; }
+            q[k][0] = src[0]; q[k][1] = src[1]; q[k][2] = src[2];
+        }
+        uint8_t* dst = tile + kPad + c * 16;
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int t = min(rsub + k * rpp, trows - 1);
+            const uint4 g = (P.dbg_skip & 8) ? make_uint4(q[k][0].x ^ q[k][1].y, q[k][0].y ^ q[k][2].x, q[k][1].z ^ q[k][2].w, q[k][0].w ^ q[k][1].x ^ q[k][2].z)
+                                             : gray16(q[k][0], q[k][1], q[k][2]);
+            uint8_t* d = dst + t * pitch;
+            *reinterpret_cast<uint4*>(d) = g;
+            if (c == 0) d[-1] = (uint8_t)(g.x >> 8);                 // pixel -1 := pixel 1
+            if (c == chunks - 1) d[16] = (uint8_t)(g.w >> 16);       // pixel w  := pixel w-2
         }
     }
-
-    // ---- phase 3: INTER_AREA horizontal partials, one float chain per (row, cell) ------
-    {
-        float* out = rowbuf + ((int64_t)f * h + r0) * AVD_HASH;
-        for (int it = tid; it < rows * AVD_HASH; it += kThreads) {
-            const int r = it >> 5, dx = it & 31;
-            const uint8_t* src = tile + (r + 1) * pitch + kPad + P.ax_begin[dx];
-            const int cnt = P.ax_count[dx];
-            if (P.area_fast) {
-                int acc = 0;
-                for (int k = 0; k < cnt; k++) acc += src[k];
-                out[it] = __int_as_float(acc);
-            } else {
-                const float wf = P.ax_first[dx], wm = P.ax_mid[dx], wl = P.ax_last[dx];
-                float acc = 0.f;
-                for (int k = 0; k < cnt; k++) {
-                    const float wgt = k == 0 ? wf : (k == cnt - 1 ? wl : wm);
-                    acc = __fadd_rn(acc, __fmul_rn((float)src[k], wgt));
-                }
-                out[it] = acc;
-            }
-        }
-    }
-
-    // ---- phase 4: INTER_LINEAR 320x320 rows whose upper source row lies in this band ---
-    {
-        const int d0 = P.band_dy[band], d1 = P.band_dy[band + 1];
-        uint8_t* dst = small + (int64_t)f * AVD_NPIX;
-        for (int it = tid; it < (d1 - d0) * AVD_SMALL; it += kThreads) {
-            const int dy = d0 + it / AVD_SMALL, dx = it % AVD_SMALL;
-            const uint8_t* ra = tile + (P.ly0[dy] - r0 + 1) * pitch + kPad;
-            const uint8_t* rb = tile + (P.ly1[dy] - r0 + 1) * pitch + kPad;
-            const int x0 = P.lx0[dx], x1 = P.lx1[dx];
-            const int a0 = P.la0[dx], a1 = P.la1[dx], b0 = P.lb0[dy], b1 = P.lb1[dy];
-            const int ha = ra[x0] * a0 + ra[x1] * a1;
-            const int hb = rb[x0] * a0 + rb[x1] * a1;
-            dst[dy * AVD_SMALL + dx] = (uint8_t)((((b0 * (ha >> 4)) >> 16) + ((b1 * (hb >> 4)) >> 16) + 2) >> 2);
-        }
-    }
-
-    // ---- block reduction of the Laplacian moments, one 64-bit atomic pair per band -----
-    long long s64 = wave_sum((long long)s_acc);
-    long long q64 = wave_sum((long long)q_acc);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s64; red[1][tid >> 6] = q64; }
     __syncthreads();
-    if (tid == 0) {
-        long long s = 0, q = 0;
-        for (int i = 0; i < kThreads / 64; i++) { s += red[0][i]; q += red[1][i]; }
-        atomicAdd(&lap_acc[2 * f], (unsigned long long)s);
-        atomicAdd(&lap_acc[2 * f + 1], (unsigned long long)q);
+    const Moments m = band_phases<kThreads, false>(tile, nullptr, P, f, band, r0, rows, tid, small, rowbuf);
+    // per-wave partial moments, summed per frame in k_hash (atomics on the 16 B/frame accumulators
+    // serialise in L2: 65 k same-line atomics cost ~50 us per launch)
+    const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
+    if ((tid & 63) == 0) {
+        long long* slot = lap_part + ((int64_t)lid * kLapSlots + (tid >> 6)) * 2;
+        slot[0] = s64; slot[1] = q64;
+    }
+}
+
+// Persistent, software-pipelined kernel for the aligned fast path (w % 16 == 0, <= 4096 px).
+// A 512-thread workgroup walks a sequence of bands.  While phases 2-4 of band k read gray tile A,
+// the 48-byte BGR chunks of band k+1 are in flight into registers (NI chunks per lane); they are
+// converted into tile B right after, so HBM latency hides behind the arithmetic of the SAME waves
+// instead of relying on other workgroups being out of phase.  One barrier per band; resampling
+// tables live in LDS so the compute phases issue no global loads that would have to retire behind
+// the prefetch.  Bands handled concurrently by the workgroups of an XCD are neighbours (halo rows
+// hit that XCD's L2).  2 workgroups x 8 waves per CU = 4 waves per SIMD (<= 128 VGPRs).
+constexpr int kPipeThreads = 512;
+
+template <int NI>
+__global__ __launch_bounds__(kPipeThreads, 4) void k_preprocess_pipe(const uint8_t* __restrict__ bgr, int n,
+                                                                    PreParams P, uint8_t* __restrict__ small,
+                                                                    float* __restrict__ rowbuf,
+                                                                    long long* __restrict__ lap_part)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int total = n * P.nbands;
+    const int h = P.h, w = P.w, pitch = P.pitch;
+    const int tid = threadIdx.x;
+    const int tile_bytes = (P.rows_per_band + 2) * pitch;
+    LdsTabs* lt = reinterpret_cast<LdsTabs*>(smem + 2 * tile_bytes);
+    for (int i = tid; i < AVD_SMALL; i += kPipeThreads) {
+        lt->lx0[i] = P.lx0[i]; lt->lx1[i] = P.lx1[i]; lt->ly0[i] = P.ly0[i]; lt->ly1[i] = P.ly1[i];
+        lt->la0[i] = P.la0[i]; lt->la1[i] = P.la1[i]; lt->lb0[i] = P.lb0[i]; lt->lb1[i] = P.lb1[i];
+    }
+    if (tid < AVD_HASH) {
+        lt->ax_begin[tid] = P.ax_begin[tid]; lt->ax_count[tid] = P.ax_count[tid];
+        lt->ax_first[tid] = P.ax_first[tid]; lt->ax_mid[tid] = P.ax_mid[tid]; lt->ax_last[tid] = P.ax_last[tid];
+    }
+    for (int i = tid; i <= P.nbands; i += kPipeThreads) lt->band_dy[i] = P.band_dy[i];
+
+    // band sequence of this workgroup: XCD x owns logical ids [x*per, (x+1)*per), its workgroups stride through it
+    const int per = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, gstride = gridDim.x >> 3;
+    const int lid_end = min((xcd + 1) * per, total);
+    int lid = xcd * per + (blockIdx.x >> 3);
+
+    const int chunks = w >> 4;
+    const int rpp = kPipeThreads / chunks;                 // tile rows covered per pass of the workgroup
+    const int rsub = tid / chunks, c = tid - rsub * chunks;
+    const bool loader = rsub < rpp;
+
+    uint4 q[NI][3];
+    auto issue = [&](int id) {
+        const int f = id / P.nbands, band = id - f * P.nbands;
+        const int r0 = band * P.rows_per_band;
+        const int trows = min(P.rows_per_band, h - r0) + 2;
+        const uint8_t* col = bgr + (int64_t)f * P.frame_stride + c * 48;
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int t = min(rsub + k * rpp, trows - 1);  // surplus items re-read the last row (same bytes)
+            const int y = reflect_once(r0 - 1 + t, h);
+            const uint4* src = reinterpret_cast<const uint4*>(col + (int64_t)y * P.row_stride);
+            q[k][0] = src[0]; q[k][1] = src[1]; q[k][2] = src[2];
+        }
+    };
+
+    if (lid < lid_end && loader) issue(lid);
+    int cur = 0;
+    for (; lid < lid_end; lid += gstride, cur ^= 1) {
+        const int f = lid / P.nbands, band = lid - f * P.nbands;
+        const int r0 = band * P.rows_per_band;
+        const int rows = min(P.rows_per_band, h - r0);
+        const int trows = rows + 2;
+        uint8_t* tile = smem + cur * tile_bytes;
+        if (loader) {
+            uint8_t* dst = tile + kPad + c * 16;
+#pragma unroll
+            for (int k = 0; k < NI; k++) {
+                const int t = min(rsub + k * rpp, trows - 1);
+                const uint4 g = gray16(q[k][0], q[k][1], q[k][2]);
+                uint8_t* d = dst + t * pitch;
+                *reinterpret_cast<uint4*>(d) = g;
+                if (c == 0) d[-1] = (uint8_t)(g.x >> 8);                 // pixel -1 := pixel 1
+                if (c == chunks - 1) d[16] = (uint8_t)(g.w >> 16);       // pixel w  := pixel w-2
+            }
+        }
+        __syncthreads();                                   // tile (and, first time, the LDS tables) complete
+        const int nxt = lid + gstride;
+        if (nxt < lid_end && loader) issue(nxt);           // in flight during the arithmetic below
+        const Moments m = band_phases<kPipeThreads, true>(tile, lt, P, f, band, r0, rows, tid, small, rowbuf);
+        const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
+        if ((tid & 63) == 0) {
+            long long* slot = lap_part + ((int64_t)lid * kLapSlots + (tid >> 6)) * 2;
+            slot[0] = s64; slot[1] = q64;
+        }
     }
 }
 
 // 32x32 INTER_AREA cells from the per-row partials (vertical accumulation in cv2's row
 // order), then aHash bits: g >= mean(g)  <=>  1024*g >= sum(g)   (video.py:7-8)
 __global__ __launch_bounds__(1024) void k_hash(const float* __restrict__ rowbuf, HashParams P,
-                                              uint8_t* __restrict__ area, uint8_t* __restrict__ bits)
+                                              uint8_t* __restrict__ area, uint8_t* __restrict__ bits,
+                                              const long long* __restrict__ lap_part, int nbands, int waves,
+                                              unsigned long long* __restrict__ lap)
 {
     __shared__ int wsum[16];
+    __shared__ long long lsum[2][16];
     const int f = blockIdx.x, tid = threadIdx.x;
+    {   // exact Laplacian moments of the frame = sum of the per-wave partials of its bands
+        long long s = 0, q = 0;
+        for (int i = tid; i < nbands * waves; i += 1024) {
+            const long long* slot = lap_part + (((int64_t)f * nbands + i / waves) * kLapSlots + i % waves) * 2;
+            s += slot[0]; q += slot[1];
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        if ((tid & 63) == 0) { lsum[0][tid >> 6] = s; lsum[1][tid >> 6] = q; }
+    }
     const int dy = tid >> 5, dx = tid & 31;
     const float* rb = rowbuf + (int64_t)f * P.h * AVD_HASH + dx;
     const int y0 = P.ay_begin[dy], cnt = P.ay_count[dy];
@@ -249,6 +502,13 @@ __global__ __launch_bounds__(1024) void k_hash(const float* __restrict__ rowbuf,
     for (int i = 0; i < 16; i++) total += wsum[i];
     area[(int64_t)f * 1024 + tid] = (uint8_t)cell;
     bits[(int64_t)f * 1024 + tid] = (uint8_t)(cell * 1024 >= total);
+    if (tid == 0) {
+        long long s = 0, q = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s += lsum[0][i]; q += lsum[1][i]; }
+        lap[2 * f] = (unsigned long long)s;
+        lap[2 * f + 1] = (unsigned long long)q;
+    }
 }
 
 // ham[f] = popcount(hash[f] ^ hash[f-1]) (video.py:38); ham[0] = -1
@@ -268,6 +528,24 @@ __global__ __launch_bounds__(256) void k_hamming(const uint8_t* __restrict__ bit
 
 }  // namespace
 
+template <int NI>
+static void launch_pipe(avd_ctx* ctx, const uint8_t* d_bgr, int n, const PreParams& P, int cus)
+{
+    Workspace& ws = ctx->ws;
+    const size_t lds = 2 * (size_t)(P.rows_per_band + 2) * P.pitch + sizeof(LdsTabs);
+    static bool opt_in = false;
+    if (!opt_in) {
+        (void)hipFuncSetAttribute((const void*)k_preprocess_pipe<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        opt_in = true;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+    const int total = n * P.nbands;
+    int grid = std::min(cus * per_cu, ((total + 7) / 8) * 8);
+    grid = std::max(8, grid & ~7);
+    hipLaunchKernelGGL(k_preprocess_pipe<NI>, dim3(grid), dim3(kPipeThreads), lds, ctx->stream, d_bgr, n, P, ws.d_small,
+                       ws.d_rowbuf, ws.d_lap_part);
+}
+
 int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
                       int64_t row_stride, int64_t frame_stride)
 {
@@ -275,18 +553,47 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
     PreParams P = ws.pre;
     P.row_stride = row_stride;
     P.frame_stride = frame_stride;
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_lap, 0, sizeof(unsigned long long) * 2 * n, ctx->stream));
+    { const char* e = std::getenv("AVD_DBG_SKIP"); P.dbg_skip = e ? std::atoi(e) : 0; }
     const int total = n * P.nbands;
-    const int grid = ((total + 7) / 8) * 8;
-    const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
     const bool vec = (w % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(d_bgr) % 16 == 0);
-    if (vec)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(grid), dim3(kThreads), lds, ctx->stream,
-                           d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap);
-    else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(grid), dim3(kThreads), lds, ctx->stream,
-                           d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap);
+    const int chunks = w >> 4;
+    const int ni = (vec && chunks <= kThreads) ? (P.rows_per_band + 2 + kThreads / chunks - 1) / (kThreads / chunks) : 0;
+    const int pipe_ni = (vec && chunks <= kThreads) ? (P.rows_per_band + 2 + kPipeThreads / chunks - 1) / (kPipeThreads / chunks) : 0;
+    static const int variant = [] { const char* e = std::getenv("AVD_PRE_VARIANT"); return e ? std::atoi(e) : 1; }();
+    const size_t lds1 = (size_t)(P.rows_per_band + 2) * P.pitch;
+    const int grid1 = ((total + 7) / 8) * 8;
+    ws.lap_waves = kThreads / 64;
+    if (variant == 1 && ni > 0 && ni <= 12) {
+#define AVD_VEC_CASE(N) hipLaunchKernelGGL(k_preprocess_vec<N>, dim3(grid1), dim3(kThreads), lds1, ctx->stream, d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part)
+        switch (ni) {
+        case 1: case 2: case 3: AVD_VEC_CASE(3); break;
+        case 4: AVD_VEC_CASE(4); break;
+        case 5: AVD_VEC_CASE(5); break;
+        case 6: AVD_VEC_CASE(6); break;
+        case 7: AVD_VEC_CASE(7); break;
+        case 8: AVD_VEC_CASE(8); break;
+        case 9: AVD_VEC_CASE(9); break;
+        case 10: AVD_VEC_CASE(10); break;
+        default: AVD_VEC_CASE(12); break;
+        }
+#undef AVD_VEC_CASE
+    } else if (variant == 2 && pipe_ni > 0 && pipe_ni <= 6 && P.nbands + 1 <= 512) {
+        ws.lap_waves = kPipeThreads / 64;
+        if (pipe_ni <= 3) launch_pipe<3>(ctx, d_bgr, n, P, ctx->num_cus);
+        else if (pipe_ni == 4) launch_pipe<4>(ctx, d_bgr, n, P, ctx->num_cus);
+        else if (pipe_ni == 5) launch_pipe<5>(ctx, d_bgr, n, P, ctx->num_cus);
+        else launch_pipe<6>(ctx, d_bgr, n, P, ctx->num_cus);
+    } else {
+        const int grid = ((total + 7) / 8) * 8;
+        const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
+        if (vec)
+            hipLaunchKernelGGL(k_preprocess<true>, dim3(grid), dim3(kThreads), lds, ctx->stream,
+                               d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part);
+        else
+            hipLaunchKernelGGL(k_preprocess<false>, dim3(grid), dim3(kThreads), lds, ctx->stream,
+                               d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -294,7 +601,8 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
 int launch_hash(avd_ctx* ctx, int n)
 {
     Workspace& ws = ctx->ws;
-    hipLaunchKernelGGL(k_hash, dim3(n), dim3(1024), 0, ctx->stream, ws.d_rowbuf, ws.hsh, ws.d_area, ws.d_hash);
+    hipLaunchKernelGGL(k_hash, dim3(n), dim3(1024), 0, ctx->stream, ws.d_rowbuf, ws.hsh, ws.d_area, ws.d_hash,
+                       (const long long*)ws.d_lap_part, ws.pre.nbands, ws.lap_waves, ws.d_lap);
     hipLaunchKernelGGL(k_hamming, dim3(n), dim3(256), 0, ctx->stream, ws.d_hash, ws.d_ham);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
