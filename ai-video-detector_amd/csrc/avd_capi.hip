@@ -29,7 +29,7 @@ int rows_per_band_for(int w)
     // LDS tile = (rows+2) * pitch bytes, kept under 48 KiB so that >= 3 workgroups fit a CU
     const int pitch = ((w + 32 + 15) / 16) * 16;
     int r = (48 * 1024) / pitch - 2;
-    int cap = 16;
+    int cap = 14;                      // 16 tile rows + LDS tables = 37 KiB at 1080p: 4 workgroups per CU
     if (const char* e = std::getenv("AVD_ROWS_PER_BAND")) cap = std::max(1, std::atoi(e));   // tuning knob
     r = std::min(r, cap);
     return std::max(r, 1);
@@ -91,8 +91,12 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
         }
         band_dy[nbands] = AVD_SMALL;
         TableBlob tb;
-        const size_t o_lx0 = tb.push(lt.x0), o_lx1 = tb.push(lt.x1), o_ly0 = tb.push(lt.y0), o_ly1 = tb.push(lt.y1);
-        const size_t o_la0 = tb.push(lt.a0), o_la1 = tb.push(lt.a1), o_lb0 = tb.push(lt.b0), o_lb1 = tb.push(lt.b1);
+        std::vector<LinTap> lxt(AVD_SMALL), lyt(AVD_SMALL);
+        for (int d = 0; d < AVD_SMALL; d++) {
+            lxt[d] = LinTap{(short)lt.x0[d], (short)lt.x1[d], lt.a0[d], lt.a1[d]};
+            lyt[d] = LinTap{(short)lt.y0[d], (short)lt.y1[d], lt.b0[d], lt.b1[d]};
+        }
+        const size_t o_lxt = tb.push(lxt), o_lyt = tb.push(lyt);
         const size_t o_band = tb.push(band_dy);
         const size_t o_axb = tb.push(at.x.begin), o_axc = tb.push(at.x.count);
         const size_t o_axf = tb.push(at.x.w_first), o_axm = tb.push(at.x.w_mid), o_axl = tb.push(at.x.w_last);
@@ -104,10 +108,7 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
         HIP_TRY(ctx, hipMemcpyAsync(dt, tb.bytes.data(), tb.bytes.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // tb goes out of scope
         PreParams& P = ws.pre;
-        P.lx0 = (const int*)(dt + o_lx0); P.lx1 = (const int*)(dt + o_lx1);
-        P.ly0 = (const int*)(dt + o_ly0); P.ly1 = (const int*)(dt + o_ly1);
-        P.la0 = (const short*)(dt + o_la0); P.la1 = (const short*)(dt + o_la1);
-        P.lb0 = (const short*)(dt + o_lb0); P.lb1 = (const short*)(dt + o_lb1);
+        P.lxt = (const LinTap*)(dt + o_lxt); P.lyt = (const LinTap*)(dt + o_lyt);
         P.band_dy = (const int*)(dt + o_band);
         P.ax_begin = (const int*)(dt + o_axb); P.ax_count = (const int*)(dt + o_axc);
         P.ax_first = (const float*)(dt + o_axf); P.ax_mid = (const float*)(dt + o_axm); P.ax_last = (const float*)(dt + o_axl);

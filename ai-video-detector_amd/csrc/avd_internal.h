@@ -49,10 +49,11 @@ struct FbConsts {
 void build_fb_consts(FbConsts& c);
 
 // ---- device-side parameter blocks ------------------------------------------------
+struct LinTap { short i0, i1, w0, w1; };   // two source indices + 11-bit weights of one output row/column
+
 struct PreParams {
-    // linear 320
-    const int *lx0, *lx1, *ly0, *ly1;
-    const short *la0, *la1, *lb0, *lb1;
+    // linear 320: packed per-column and per-row taps
+    const LinTap *lxt, *lyt;           // [320] each
     const int* band_dy;                // [nbands+1] first dy owned by each band
     // area x axis (32 entries)
     const int *ax_begin, *ax_count;

@@ -14,6 +14,13 @@
 // fixed-point gray conversion into an LDS tile of uint8; phases 2-4 read only LDS.
 // Consecutive bands of a frame are placed on the same XCD (blockIdx remap) so the
 // halo rows hit that XCD's L2.
+//
+// Measured design notes (profiles/r01_preprocess_ablation.md): byte ops (v_dot4_u32_u8,
+// v_alignbyte, v_perm) issue at half rate on gfx950, the kernel is balanced between the load
+// path (0.13 ms alone) and the arithmetic (0.14 ms alone); persistent software-pipelined
+// variants (next band's loads in flight in registers during the arithmetic, 256 or 512 threads)
+// were built and were 30-40 % SLOWER than many small independent workgroups (4 per CU): the
+// dependent float chains of INTER_AREA want thread-level parallelism more than prefetch.
 #include <algorithm>
 #include <cstdlib>
 #include "avd_internal.h"
@@ -101,12 +108,25 @@ struct Moments { long long s, q; };
 // compute phases issue no global LOADS (the pipelined kernel keeps the next band's loads in flight
 // here, and vmcnt retires in order).
 struct LdsTabs {
-    int lx0[AVD_SMALL], lx1[AVD_SMALL], ly0[AVD_SMALL], ly1[AVD_SMALL];
-    short la0[AVD_SMALL], la1[AVD_SMALL], lb0[AVD_SMALL], lb1[AVD_SMALL];
+    LinTap lxt[AVD_SMALL], lyt[AVD_SMALL];
     int ax_begin[AVD_HASH], ax_count[AVD_HASH];
     float ax_first[AVD_HASH], ax_mid[AVD_HASH], ax_last[AVD_HASH];
-    int band_dy[512];
 };
+
+template <int NT>
+__device__ __forceinline__ void fill_lds_tabs(LdsTabs* lt, const PreParams& P, int tid)
+{
+    const uint2* sx = reinterpret_cast<const uint2*>(P.lxt);
+    const uint2* sy = reinterpret_cast<const uint2*>(P.lyt);
+    for (int i = tid; i < AVD_SMALL; i += NT) {
+        reinterpret_cast<uint2*>(lt->lxt)[i] = sx[i];
+        reinterpret_cast<uint2*>(lt->lyt)[i] = sy[i];
+    }
+    if (tid < AVD_HASH) {
+        lt->ax_begin[tid] = P.ax_begin[tid]; lt->ax_count[tid] = P.ax_count[tid];
+        lt->ax_first[tid] = P.ax_first[tid]; lt->ax_mid[tid] = P.ax_mid[tid]; lt->ax_last[tid] = P.ax_last[tid];
+    }
+}
 
 template <int NT, bool LTAB>
 __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTabs* lt, const PreParams& P, int f,
@@ -194,56 +214,70 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
     }
 
     // ---- INTER_AREA horizontal partials, one float chain per (row, cell), cv2's order ----
+    // The chain of a cell is sequential by definition (float adds in cv2's order); a lane runs the
+    // chains of two different rows interleaved so that dependent adds of one hide behind the other.
     if (!(P.dbg_skip & 2)) {
         float* out = rowbuf + ((int64_t)f * h + r0) * AVD_HASH;
-        for (int it = tid; it < rows * AVD_HASH; it += kThreads) {
-            const int r = it >> 5, dx = it & 31;
-            const uint8_t* src = tile + (r + 1) * pitch + kPad + (LTAB ? lt->ax_begin[dx] : P.ax_begin[dx]);
-            const int cnt = LTAB ? lt->ax_count[dx] : P.ax_count[dx];
+        const int dx = tid & 31;
+        const int xb = LTAB ? lt->ax_begin[dx] : P.ax_begin[dx];
+        const int cnt = LTAB ? lt->ax_count[dx] : P.ax_count[dx];
+        const float wf = LTAB ? lt->ax_first[dx] : P.ax_first[dx], wm = LTAB ? lt->ax_mid[dx] : P.ax_mid[dx],
+                    wl = LTAB ? lt->ax_last[dx] : P.ax_last[dx];
+        constexpr int RSTEP = kThreads / AVD_HASH;             // rows covered per pass
+        for (int ra = tid >> 5; ra < rows; ra += 2 * RSTEP) {
+            const int rb = ra + RSTEP;
+            const bool two = rb < rows;
+            const uint8_t* sa = tile + (ra + 1) * pitch + kPad + xb;
+            const uint8_t* sb = tile + ((two ? rb : ra) + 1) * pitch + kPad + xb;
             if (P.area_fast) {
-                int acc = 0;
-                for (int k = 0; k < cnt; k++) acc += src[k];
-                out[it] = __int_as_float(acc);
+                int a0 = 0, a1 = 0;
+                for (int k = 0; k < cnt; k++) { a0 += sa[k]; a1 += sb[k]; }
+                out[ra * AVD_HASH + dx] = __int_as_float(a0);
+                if (two) out[rb * AVD_HASH + dx] = __int_as_float(a1);
             } else if (P.area_x_uniform4) {
                 // every cell starts on a 4-byte boundary, spans a multiple of 4 pixels, one weight
-                const float wgt = LTAB ? lt->ax_mid[dx] : P.ax_mid[dx];
-                const unsigned* s4 = reinterpret_cast<const unsigned*>(src);
-                float acc = 0.f;
+                const unsigned* a4 = reinterpret_cast<const unsigned*>(sa);
+                const unsigned* b4 = reinterpret_cast<const unsigned*>(sb);
+                float a0 = 0.f, a1 = 0.f;
                 for (int k = 0; k < (cnt >> 2); k++) {
-                    const unsigned v = s4[k];
-                    acc = __fadd_rn(acc, __fmul_rn((float)(v & 0xFF), wgt));
-                    acc = __fadd_rn(acc, __fmul_rn((float)((v >> 8) & 0xFF), wgt));
-                    acc = __fadd_rn(acc, __fmul_rn((float)((v >> 16) & 0xFF), wgt));
-                    acc = __fadd_rn(acc, __fmul_rn((float)(v >> 24), wgt));
+                    const unsigned va = a4[k], vb = b4[k];
+                    a0 = __fadd_rn(a0, __fmul_rn((float)(va & 0xFF), wm));
+                    a1 = __fadd_rn(a1, __fmul_rn((float)(vb & 0xFF), wm));
+                    a0 = __fadd_rn(a0, __fmul_rn((float)((va >> 8) & 0xFF), wm));
+                    a1 = __fadd_rn(a1, __fmul_rn((float)((vb >> 8) & 0xFF), wm));
+                    a0 = __fadd_rn(a0, __fmul_rn((float)((va >> 16) & 0xFF), wm));
+                    a1 = __fadd_rn(a1, __fmul_rn((float)((vb >> 16) & 0xFF), wm));
+                    a0 = __fadd_rn(a0, __fmul_rn((float)(va >> 24), wm));
+                    a1 = __fadd_rn(a1, __fmul_rn((float)(vb >> 24), wm));
                 }
-                out[it] = acc;
+                out[ra * AVD_HASH + dx] = a0;
+                if (two) out[rb * AVD_HASH + dx] = a1;
             } else {
-                const float wf = LTAB ? lt->ax_first[dx] : P.ax_first[dx], wm = LTAB ? lt->ax_mid[dx] : P.ax_mid[dx],
-                            wl = LTAB ? lt->ax_last[dx] : P.ax_last[dx];
-                float acc = 0.f;
+                float a0 = 0.f, a1 = 0.f;
                 for (int k = 0; k < cnt; k++) {
                     const float wgt = k == 0 ? wf : (k == cnt - 1 ? wl : wm);
-                    acc = __fadd_rn(acc, __fmul_rn((float)src[k], wgt));
+                    a0 = __fadd_rn(a0, __fmul_rn((float)sa[k], wgt));
+                    a1 = __fadd_rn(a1, __fmul_rn((float)sb[k], wgt));
                 }
-                out[it] = acc;
+                out[ra * AVD_HASH + dx] = a0;
+                if (two) out[rb * AVD_HASH + dx] = a1;
             }
         }
     }
 
     // ---- INTER_LINEAR 320x320 rows whose upper source row lies in this band ----------------
     if (!(P.dbg_skip & 4)) {
-        const int d0 = LTAB ? lt->band_dy[band] : P.band_dy[band], d1 = LTAB ? lt->band_dy[band + 1] : P.band_dy[band + 1];
+        const int d0 = P.band_dy[band], d1 = P.band_dy[band + 1];        // wave-uniform scalar loads
         uint8_t* dst = small + (int64_t)f * AVD_NPIX;
         for (int it = tid; it < (d1 - d0) * AVD_SMALL; it += kThreads) {
-            const int dy = d0 + it / AVD_SMALL, dx = it % AVD_SMALL;
-            const uint8_t* ra = tile + ((LTAB ? lt->ly0[dy] : P.ly0[dy]) - r0 + 1) * pitch + kPad;
-            const uint8_t* rb = tile + ((LTAB ? lt->ly1[dy] : P.ly1[dy]) - r0 + 1) * pitch + kPad;
-            const int x0 = LTAB ? lt->lx0[dx] : P.lx0[dx], x1 = LTAB ? lt->lx1[dx] : P.lx1[dx];
-            const int a0 = LTAB ? lt->la0[dx] : P.la0[dx], a1 = LTAB ? lt->la1[dx] : P.la1[dx];
-            const int b0 = LTAB ? lt->lb0[dy] : P.lb0[dy], b1 = LTAB ? lt->lb1[dy] : P.lb1[dy];
-            const int ha = ra[x0] * a0 + ra[x1] * a1;
-            const int hb = rb[x0] * a0 + rb[x1] * a1;
-            dst[dy * AVD_SMALL + dx] = (uint8_t)((((b0 * (ha >> 4)) >> 16) + ((b1 * (hb >> 4)) >> 16) + 2) >> 2);
+            const int dyi = it / AVD_SMALL, dx = it - dyi * AVD_SMALL, dy = d0 + dyi;
+            const LinTap tx = LTAB ? lt->lxt[dx] : P.lxt[dx];
+            const LinTap ty = LTAB ? lt->lyt[dy] : P.lyt[dy];
+            const uint8_t* ra = tile + (ty.i0 - r0 + 1) * pitch + kPad;
+            const uint8_t* rb = tile + (ty.i1 - r0 + 1) * pitch + kPad;
+            const int ha = ra[tx.i0] * tx.w0 + ra[tx.i1] * tx.w1;
+            const int hb = rb[tx.i0] * tx.w0 + rb[tx.i1] * tx.w1;
+            dst[dy * AVD_SMALL + dx] = (uint8_t)((((ty.w0 * (ha >> 4)) >> 16) + ((ty.w1 * (hb >> 4)) >> 16) + 2) >> 2);
         }
     }
     Moments m;
@@ -328,6 +362,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_preprocess_vec(const uint8_t* _
     const int chunks = w >> 4;
     const int rpp = kThreads / chunks;                     // tile rows covered per pass of the workgroup
     const int rsub = tid / chunks, c = tid - rsub * chunks;
+    LdsTabs* lt = reinterpret_cast<LdsTabs*>(tile + (P.rows_per_band + 2) * pitch);
+    fill_lds_tabs<kThreads>(lt, P, tid);
     if (rsub < rpp) {
         const uint8_t* col = bgr + (int64_t)f * P.frame_stride + c * 48;
         uint4 q[NI][3];
@@ -352,103 +388,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_preprocess_vec(const uint8_t* _
         }
     }
     __syncthreads();
-    const Moments m = band_phases<kThreads, false>(tile, nullptr, P, f, band, r0, rows, tid, small, rowbuf);
+    const Moments m = band_phases<kThreads, true>(tile, lt, P, f, band, r0, rows, tid, small, rowbuf);
     // per-wave partial moments, summed per frame in k_hash (atomics on the 16 B/frame accumulators
     // serialise in L2: 65 k same-line atomics cost ~50 us per launch)
     const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
     if ((tid & 63) == 0) {
         long long* slot = lap_part + ((int64_t)lid * kLapSlots + (tid >> 6)) * 2;
         slot[0] = s64; slot[1] = q64;
-    }
-}
-
-// Persistent, software-pipelined kernel for the aligned fast path (w % 16 == 0, <= 4096 px).
-// A 512-thread workgroup walks a sequence of bands.  While phases 2-4 of band k read gray tile A,
-// the 48-byte BGR chunks of band k+1 are in flight into registers (NI chunks per lane); they are
-// converted into tile B right after, so HBM latency hides behind the arithmetic of the SAME waves
-// instead of relying on other workgroups being out of phase.  One barrier per band; resampling
-// tables live in LDS so the compute phases issue no global loads that would have to retire behind
-// the prefetch.  Bands handled concurrently by the workgroups of an XCD are neighbours (halo rows
-// hit that XCD's L2).  2 workgroups x 8 waves per CU = 4 waves per SIMD (<= 128 VGPRs).
-constexpr int kPipeThreads = 512;
-
-template <int NI>
-__global__ __launch_bounds__(kPipeThreads, 4) void k_preprocess_pipe(const uint8_t* __restrict__ bgr, int n,
-                                                                    PreParams P, uint8_t* __restrict__ small,
-                                                                    float* __restrict__ rowbuf,
-                                                                    long long* __restrict__ lap_part)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int total = n * P.nbands;
-    const int h = P.h, w = P.w, pitch = P.pitch;
-    const int tid = threadIdx.x;
-    const int tile_bytes = (P.rows_per_band + 2) * pitch;
-    LdsTabs* lt = reinterpret_cast<LdsTabs*>(smem + 2 * tile_bytes);
-    for (int i = tid; i < AVD_SMALL; i += kPipeThreads) {
-        lt->lx0[i] = P.lx0[i]; lt->lx1[i] = P.lx1[i]; lt->ly0[i] = P.ly0[i]; lt->ly1[i] = P.ly1[i];
-        lt->la0[i] = P.la0[i]; lt->la1[i] = P.la1[i]; lt->lb0[i] = P.lb0[i]; lt->lb1[i] = P.lb1[i];
-    }
-    if (tid < AVD_HASH) {
-        lt->ax_begin[tid] = P.ax_begin[tid]; lt->ax_count[tid] = P.ax_count[tid];
-        lt->ax_first[tid] = P.ax_first[tid]; lt->ax_mid[tid] = P.ax_mid[tid]; lt->ax_last[tid] = P.ax_last[tid];
-    }
-    for (int i = tid; i <= P.nbands; i += kPipeThreads) lt->band_dy[i] = P.band_dy[i];
-
-    // band sequence of this workgroup: XCD x owns logical ids [x*per, (x+1)*per), its workgroups stride through it
-    const int per = (total + 7) >> 3;
-    const int xcd = blockIdx.x & 7, gstride = gridDim.x >> 3;
-    const int lid_end = min((xcd + 1) * per, total);
-    int lid = xcd * per + (blockIdx.x >> 3);
-
-    const int chunks = w >> 4;
-    const int rpp = kPipeThreads / chunks;                 // tile rows covered per pass of the workgroup
-    const int rsub = tid / chunks, c = tid - rsub * chunks;
-    const bool loader = rsub < rpp;
-
-    uint4 q[NI][3];
-    auto issue = [&](int id) {
-        const int f = id / P.nbands, band = id - f * P.nbands;
-        const int r0 = band * P.rows_per_band;
-        const int trows = min(P.rows_per_band, h - r0) + 2;
-        const uint8_t* col = bgr + (int64_t)f * P.frame_stride + c * 48;
-#pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int t = min(rsub + k * rpp, trows - 1);  // surplus items re-read the last row (same bytes)
-            const int y = reflect_once(r0 - 1 + t, h);
-            const uint4* src = reinterpret_cast<const uint4*>(col + (int64_t)y * P.row_stride);
-            q[k][0] = src[0]; q[k][1] = src[1]; q[k][2] = src[2];
-        }
-    };
-
-    if (lid < lid_end && loader) issue(lid);
-    int cur = 0;
-    for (; lid < lid_end; lid += gstride, cur ^= 1) {
-        const int f = lid / P.nbands, band = lid - f * P.nbands;
-        const int r0 = band * P.rows_per_band;
-        const int rows = min(P.rows_per_band, h - r0);
-        const int trows = rows + 2;
-        uint8_t* tile = smem + cur * tile_bytes;
-        if (loader) {
-            uint8_t* dst = tile + kPad + c * 16;
-#pragma unroll
-            for (int k = 0; k < NI; k++) {
-                const int t = min(rsub + k * rpp, trows - 1);
-                const uint4 g = gray16(q[k][0], q[k][1], q[k][2]);
-                uint8_t* d = dst + t * pitch;
-                *reinterpret_cast<uint4*>(d) = g;
-                if (c == 0) d[-1] = (uint8_t)(g.x >> 8);                 // pixel -1 := pixel 1
-                if (c == chunks - 1) d[16] = (uint8_t)(g.w >> 16);       // pixel w  := pixel w-2
-            }
-        }
-        __syncthreads();                                   // tile (and, first time, the LDS tables) complete
-        const int nxt = lid + gstride;
-        if (nxt < lid_end && loader) issue(nxt);           // in flight during the arithmetic below
-        const Moments m = band_phases<kPipeThreads, true>(tile, lt, P, f, band, r0, rows, tid, small, rowbuf);
-        const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
-        if ((tid & 63) == 0) {
-            long long* slot = lap_part + ((int64_t)lid * kLapSlots + (tid >> 6)) * 2;
-            slot[0] = s64; slot[1] = q64;
-        }
     }
 }
 
@@ -528,24 +474,6 @@ __global__ __launch_bounds__(256) void k_hamming(const uint8_t* __restrict__ bit
 
 }  // namespace
 
-template <int NI>
-static void launch_pipe(avd_ctx* ctx, const uint8_t* d_bgr, int n, const PreParams& P, int cus)
-{
-    Workspace& ws = ctx->ws;
-    const size_t lds = 2 * (size_t)(P.rows_per_band + 2) * P.pitch + sizeof(LdsTabs);
-    static bool opt_in = false;
-    if (!opt_in) {
-        (void)hipFuncSetAttribute((const void*)k_preprocess_pipe<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        opt_in = true;
-    }
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
-    const int total = n * P.nbands;
-    int grid = std::min(cus * per_cu, ((total + 7) / 8) * 8);
-    grid = std::max(8, grid & ~7);
-    hipLaunchKernelGGL(k_preprocess_pipe<NI>, dim3(grid), dim3(kPipeThreads), lds, ctx->stream, d_bgr, n, P, ws.d_small,
-                       ws.d_rowbuf, ws.d_lap_part);
-}
-
 int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
                       int64_t row_stride, int64_t frame_stride)
 {
@@ -553,19 +481,22 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
     PreParams P = ws.pre;
     P.row_stride = row_stride;
     P.frame_stride = frame_stride;
+#ifdef AVD_TIMING_EXPERIMENTS      // make EXTRA=-DAVD_TIMING_EXPERIMENTS: phase ablation (results are WRONG with a non-zero mask)
     { const char* e = std::getenv("AVD_DBG_SKIP"); P.dbg_skip = e ? std::atoi(e) : 0; }
+#else
+    P.dbg_skip = 0;
+#endif
     const int total = n * P.nbands;
     const bool vec = (w % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(d_bgr) % 16 == 0);
     const int chunks = w >> 4;
     const int ni = (vec && chunks <= kThreads) ? (P.rows_per_band + 2 + kThreads / chunks - 1) / (kThreads / chunks) : 0;
-    const int pipe_ni = (vec && chunks <= kThreads) ? (P.rows_per_band + 2 + kPipeThreads / chunks - 1) / (kPipeThreads / chunks) : 0;
-    static const int variant = [] { const char* e = std::getenv("AVD_PRE_VARIANT"); return e ? std::atoi(e) : 1; }();
     const size_t lds1 = (size_t)(P.rows_per_band + 2) * P.pitch;
+    const size_t lds_vec = lds1 + sizeof(LdsTabs);
     const int grid1 = ((total + 7) / 8) * 8;
     ws.lap_waves = kThreads / 64;
-    if (variant == 1 && ni > 0 && ni <= 12) {
-#define AVD_VEC_CASE(N) hipLaunchKernelGGL(k_preprocess_vec<N>, dim3(grid1), dim3(kThreads), lds1, ctx->stream, d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part)
+    if (ni > 0 && ni <= 9) {
+#define AVD_VEC_CASE(N) hipLaunchKernelGGL(k_preprocess_vec<N>, dim3(grid1), dim3(kThreads), lds_vec, ctx->stream, d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part)
         switch (ni) {
         case 1: case 2: case 3: AVD_VEC_CASE(3); break;
         case 4: AVD_VEC_CASE(4); break;
@@ -574,16 +505,9 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
         case 7: AVD_VEC_CASE(7); break;
         case 8: AVD_VEC_CASE(8); break;
         case 9: AVD_VEC_CASE(9); break;
-        case 10: AVD_VEC_CASE(10); break;
-        default: AVD_VEC_CASE(12); break;
+        default: AVD_VEC_CASE(9); break;
         }
 #undef AVD_VEC_CASE
-    } else if (variant == 2 && pipe_ni > 0 && pipe_ni <= 6 && P.nbands + 1 <= 512) {
-        ws.lap_waves = kPipeThreads / 64;
-        if (pipe_ni <= 3) launch_pipe<3>(ctx, d_bgr, n, P, ctx->num_cus);
-        else if (pipe_ni == 4) launch_pipe<4>(ctx, d_bgr, n, P, ctx->num_cus);
-        else if (pipe_ni == 5) launch_pipe<5>(ctx, d_bgr, n, P, ctx->num_cus);
-        else launch_pipe<6>(ctx, d_bgr, n, P, ctx->num_cus);
     } else {
         const int grid = ((total + 7) / 8) * 8;
         const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
