@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_pyr_col(const float* __restrict__ tmp, 
 // ---------------------------------------------------------------------------------------
 // FarnebackPolyExp (poly_n = 5): one workgroup per image row.  Vertical 11-tap pass in
 // float into LDS (3 moment planes, replicate border), horizontal pass with double
-// accumulators, output 5 planar coefficient planes R[c][y][x].
+// accumulators, output 5 interleaved coefficients R[y][x][c].
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, int w, int h,
                                                 const FbConsts* __restrict__ C, float* __restrict__ R)
@@ -146,13 +146,14 @@ __global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, in
         b6 += (double)((r1[k] - r1[-k]) * xg[k]);
         b5 += (double)((r2[k] + r2[-k]) * g[k]);
     }
-    const int64_t plane = (int64_t)w * h;
-    float* out = R + (int64_t)f * 5 * plane + y * w + x;
+    // interleaved [y][x][5] (cv2's own layout): k_uv gathers all five coefficients of a pixel and of
+    // its right-hand neighbour as ten consecutive floats
+    float* out = R + ((int64_t)f * w * h + y * w + x) * 5;
     out[0] = (float)(b3 * C->ig11);
-    out[plane] = (float)(b2 * C->ig11);
-    out[2 * plane] = (float)(b1 * C->ig03 + b5 * C->ig33);
-    out[3 * plane] = (float)(b1 * C->ig03 + b4 * C->ig33);
-    out[4 * plane] = (float)(b6 * C->ig55);
+    out[1] = (float)(b2 * C->ig11);
+    out[2] = (float)(b1 * C->ig03 + b5 * C->ig33);
+    out[3] = (float)(b1 * C->ig03 + b4 * C->ig33);
+    out[4] = (float)(b6 * C->ig55);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -194,73 +195,6 @@ __global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev,
 }
 
 // ---------------------------------------------------------------------------------------
-// FarnebackUpdateMatrices for one pixel: warp R1 by the current flow (bilinear), build the
-// five entries (G11, G12, G22, h1, h2) of the 2x2 normal equations.  R planes
-// [frame][5][h][w]; flow planes [pair][2][h][w].
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void normal_eq(const float* __restrict__ R0p, const float* __restrict__ R1p,
-                                          const float* __restrict__ flp, int x, int y, int w, int h,
-                                          float (&M)[5])
-{
-    const int plane = w * h;
-    const float* R0 = R0p + y * w + x;
-    const float dx = flp[y * w + x], dy = flp[plane + y * w + x];
-    float fx = x + dx, fy = y + dy;
-    const int x1 = floor_f(fx), y1 = floor_f(fy);
-    float r2, r3, r4, r5, r6;
-    fx -= x1; fy -= y1;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float* q = R1p + y1 * w + x1;
-        r2 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
-        r3 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
-        r4 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
-        r5 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1]; q += plane;
-        r6 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
-        r4 = (R0[2 * plane] + r4) * 0.5f;
-        r5 = (R0[3 * plane] + r5) * 0.5f;
-        r6 = (R0[4 * plane] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = R0[2 * plane];
-        r5 = R0[3 * plane];
-        r6 = R0[4 * plane] * 0.5f;
-    }
-    r2 = (R0[0] - r2) * 0.5f;
-    r3 = (R0[plane] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
-        auto border = [](int d) { return d < 2 ? 0.14f : 0.4472f; };      // {.14,.14,.4472,.4472,.4472}
-        const float scale = (x < 5 ? border(x) : 1.f) * (x >= w - 5 ? border(w - x - 1) : 1.f) *
-                            (y < 5 ? border(y) : 1.f) * (y >= h - 5 ? border(h - y - 1) : 1.f);
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    }
-    M[0] = r4 * r4 + r6 * r6;
-    M[1] = (r4 + r5) * r6;
-    M[2] = r5 * r5 + r6 * r6;
-    M[3] = r4 * r2 + r6 * r3;
-    M[4] = r6 * r2 + r5 * r3;
-}
-
-// pointwise launch of normal_eq: M planes [pair][5][h][w]
-__global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R, const float* __restrict__ flow,
-                                                        float* __restrict__ M, int w, int h, int npairs)
-{
-    const int64_t plane = (int64_t)w * h;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= npairs * plane) return;
-    const int x = (int)(gid % w);
-    const int y = (int)((gid / w) % h);
-    const int p = (int)(gid / plane);
-    float m[5];
-    normal_eq(R + (int64_t)p * 5 * plane, R + (int64_t)(p + 1) * 5 * plane, flow + (int64_t)p * 2 * plane, x, y, w, h, m);
-    float* out = M + (int64_t)p * 5 * plane + y * w + x;
-#pragma unroll
-    for (int c = 0; c < 5; c++) out[c * plane] = m[c];
-}
-
-// ---------------------------------------------------------------------------------------
 // FarnebackUpdateFlow_Blur, winsize 15 (m = 7).  cv2 keeps RUNNING box sums in double and
 // rounds at every slide, so the value at (y,x) depends on the whole column / row prefix; the
 // chains are reproduced literally, one lane per chain, in two kernels:
@@ -284,92 +218,171 @@ constexpr int kStripW = 48;          // output columns per wave in k_vd: 64 lane
 __host__ __device__ constexpr int d16_xch(int w) { return (w + 7) / 8; }
 __host__ __device__ constexpr int d16_nyb(int h) { return (h + 63) / 64; }
 
+// ---------------------------------------------------------------------------------------
+// k_uv = k_update_matrices fused into k_vd: every lane evaluates the normal equations of its
+// column row by row and feeds them straight into the vertical running sums, so the five M
+// planes never exist in memory.  A row's evaluation needs two dependent memory round trips
+// (flow/R0, then the bilinear gather of R1 at the warped position); they are software
+// pipelined by hand: at the step that consumes row r, the gathers of row r+2 and the flow/R0
+// loads of row r+4 are issued (explicit register stages -- the compiler does not hoist loads
+// across the predicated stores).  vsum(x+7)/vsum(x-8) are exchanged through a wave-private LDS
+// row (ds_bpermute costs ~20 cycles per wave64 on gfx950, an LDS write + two reads ~1/3 of that).
+// ---------------------------------------------------------------------------------------
+struct NeIn { float dx, dy, r0[5]; };
+struct NeG { float top[10], bot[10]; };            // (y1,x1..x1+1) and (y1+1,x1..x1+1), 5 coefficients each
+
+struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
+struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+
+// R is interleaved [frame][y][x][5]; flow planar [pair][2][y][x].  Addressing is "uniform base +
+// 32-bit element offset" (R spans < 2^30 floats), wide loads on 4-byte-aligned addresses.
+__device__ __forceinline__ void ne_load(const float* __restrict__ R, const float* __restrict__ flow, unsigned r0base,
+                                        unsigned flbase, int x, int y, int w, int plane, NeIn& in)
+{
+    const unsigned o = (unsigned)(y * w + x);
+    in.dx = flow[flbase + o]; in.dy = flow[flbase + plane + o];
+    const float* p = R + (r0base + o * 5u);
+    const F4 v = *reinterpret_cast<const F4*>(p);
+    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = p[4];
+}
+
+// gather the four bilinear neighbours of the warped position (clamped address when outside:
+// the values are discarded by ne_finish, exactly as cv2 takes the "else" branch there)
+__device__ __forceinline__ void ne_gather(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
+                                          int w, int h, int plane, NeG& g)
+{
+    const float fx = x + in.dx, fy = y + in.dy;
+    const int x1 = clampi(floor_f(fx), 0, w - 2), y1 = clampi(floor_f(fy), 0, h - 2);
+    const float* p = R + (r1base + (unsigned)(y1 * w + x1) * 5u);
+    const float* q = p + w * 5;
+    const F4 t0 = *reinterpret_cast<const F4*>(p), t1 = *reinterpret_cast<const F4*>(p + 4);
+    const F2 t2 = *reinterpret_cast<const F2*>(p + 8);
+    const F4 b0 = *reinterpret_cast<const F4*>(q), b1 = *reinterpret_cast<const F4*>(q + 4);
+    const F2 b2 = *reinterpret_cast<const F2*>(q + 8);
+    g.top[0] = t0.a; g.top[1] = t0.b; g.top[2] = t0.c; g.top[3] = t0.d; g.top[4] = t1.a;
+    g.top[5] = t1.b; g.top[6] = t1.c; g.top[7] = t1.d; g.top[8] = t2.a; g.top[9] = t2.b;
+    g.bot[0] = b0.a; g.bot[1] = b0.b; g.bot[2] = b0.c; g.bot[3] = b0.d; g.bot[4] = b1.a;
+    g.bot[5] = b1.b; g.bot[6] = b1.c; g.bot[7] = b1.d; g.bot[8] = b2.a; g.bot[9] = b2.b;
+}
+
+__device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, int y, int w, int h, float (&M)[5])
+{
+    const float dx = in.dx, dy = in.dy;
+    float fx = x + dx, fy = y + dy;
+    const int x1 = floor_f(fx), y1 = floor_f(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1; fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
+        r3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
+        r4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
+        r5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
+        r6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
+        r4 = (in.r0[2] + r4) * 0.5f;
+        r5 = (in.r0[3] + r5) * 0.5f;
+        r6 = (in.r0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = in.r0[2];
+        r5 = in.r0[3];
+        r6 = in.r0[4] * 0.5f;
+    }
+    r2 = (in.r0[0] - r2) * 0.5f;
+    r3 = (in.r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
+        auto border = [](int d) { return d < 2 ? 0.14f : 0.4472f; };      // {.14,.14,.4472,.4472,.4472}
+        const float scale = (x < 5 ? border(x) : 1.f) * (x >= w - 5 ? border(w - x - 1) : 1.f) *
+                            (y < 5 ? border(y) : 1.f) * (y >= h - 5 ? border(h - y - 1) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
 template <int W>
-__global__ __launch_bounds__(256) void k_vd(const float* __restrict__ M, double* __restrict__ D16,
-                                           double* __restrict__ VS0, int npairs)
+__global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const float* __restrict__ flow,
+                                           double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W), NYB = d16_nyb(H);
-    constexpr int64_t plane = (int64_t)W * H;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int plane = W * H;
+    __shared__ double xch[4][5][64];
+    const int wv = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wv;
     if (wid >= npairs * NSTRIP) return;
     const int lane = threadIdx.x & 63;
     const int p = wid / NSTRIP, strip = wid - p * NSTRIP;
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
-    const float* Mp = M + (int64_t)p * 5 * plane + x;
+    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;   // R[frame p], R[frame p+1]
     const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
     const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-    double* Dt = D16 + ((int64_t)p * NYB * 5 * XCH + (x >> 3)) * 512;        // tile column of this lane
-    double* V0 = VS0 + (int64_t)p * 5 * H * 8 + (lane - 8);
-    const int xs = x & 7;
+    const unsigned dbase = ((unsigned)p * NYB * 5 * XCH + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+    const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+    double (*xw)[64] = xch[wv];
+    const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
 
-    // Rows y-8 .. y+7 of this column live in a register ring (slot = row & 15) so every M value
-    // is loaded once; loads run one 4-row sub-block ahead of the arithmetic (explicit prefetch:
-    // the compiler will not hoist loads across the predicated stores on its own).
-    float ring[16][5];
+    float ring[16][5];                                  // rows y-8 .. y+7, slot = row & 15
     double vs[5];
+    // software pipeline registers, static slots: inputs of rows r..r+3 in in[(j..j+3)&3], gathered
+    // neighbours of rows r, r+1 in g[j&1], g[(j+1)&1]  (j = step index mod 16, r = entering row)
+    NeIn in[4]; NeG g[2];
 #pragma unroll
-    for (int r = 0; r < m; r++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) ring[r][c] = Mp[c * plane + r * W];
+    for (int r = 0; r < m; r++) {
+        ne_load(R, flow, r0base, flbase, x, r, W, plane, in[0]);
+        ne_gather(R, r1base, in[0], x, r, W, H, plane, g[0]);
+        ne_finish(in[0], g[0], x, r, W, H, ring[r]);
+    }
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         vs[c] = (double)(ring[0][c] * (float)(m + 2));
 #pragma unroll
         for (int r = 1; r < m; r++) vs[c] += (double)ring[r][c];
     }
-    float pf[4][5];                                       // entering rows of the current sub-block
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) pf[j][c] = Mp[c * plane + min(j + m, H - 1) * W];
+    for (int k = 0; k < 4; k++) ne_load(R, flow, r0base, flbase, x, min(m + k, H - 1), W, plane, in[k]);
+    ne_gather(R, r1base, in[0], x, m, W, H, plane, g[0]);
+    ne_gather(R, r1base, in[1], x, min(m + 1, H - 1), W, H, plane, g[1]);
 
     for (int yb = 0; yb < H; yb += 16) {
 #pragma unroll
-        for (int sb = 0; sb < 4; sb++) {
-            const int y0 = yb + sb * 4;
-            if (y0 < H) {                                 // only false in the tail block of H = 40
-                float nx[4][5];
+        for (int j = 0; j < 16; j++) {
+            const int y = yb + j;
+            if (y < H) {                                 // only false in the tail block of H = 40
+                const int r = min(y + m, H - 1);         // entering row (clamped: its value is M(H-1) again)
+                float a[5];
+                ne_finish(in[j & 3], g[j & 1], x, r, W, H, a);
+                // refill the two slots just consumed: gathers of row r+2, inputs of row r+4
+                ne_gather(R, r1base, in[(j + 2) & 3], x, min(r + 2, H - 1), W, H, plane, g[j & 1]);
+                ne_load(R, flow, r0base, flbase, x, min(r + 4, H - 1), W, plane, in[j & 3]);
+                double dv[5];
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int c = 0; c < 5; c++) nx[j][c] = Mp[c * plane + min(y0 + 4 + j + m, H - 1) * W];
-                double dv[4][5], hv[4][5];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int y = y0 + j;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        const float a = pf[j][c];         // row min(y+7, H-1)
-                        const float b = y >= m + 1 ? ring[(sb * 4 + j + 8) & 15][c] : ring[0][c];
-                        ring[(sb * 4 + j + m) & 15][c] = a;
-                        vs[c] += (double)(a - b);
-                        const double hi = __shfl(vs[c], lane + m, 64);
-                        const double lo = __shfl(vs[c], lane - m - 1, 64);
-                        dv[j][c] = hi - lo;
-                        hv[j][c] = vs[c];
-                    }
+                for (int c = 0; c < 5; c++) {
+                    const float b = y >= m + 1 ? ring[(j + 8) & 15][c] : ring[0][c];
+                    ring[(j + m) & 15][c] = a[c];
+                    vs[c] += (double)(a[c] - b);
+                    xw[c][lane] = vs[c];
                 }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 5; c++) dv[c] = xw[c][lhi] - xw[c][llo];
+                __builtin_amdgcn_wave_barrier();
                 if (writer) {
+                    const unsigned trow = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8;
+                    const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int y = y0 + j;
-                        const int64_t trow = ((int64_t)(y >> 6) * 5 * XCH) * 512 + (y & 63) * 8 + (xs ^ (y & 7));
-#pragma unroll
-                        for (int c = 0; c < 5; c++) Dt[trow + (int64_t)c * XCH * 512] = dv[j][c];
-                    }
+                    for (int c = 0; c < 5; c++) D16[trow + sw + (unsigned)c * XCH * 512u] = dv[c];
                 }
                 if (head) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-#pragma unroll
-                        for (int c = 0; c < 5; c++) V0[(c * H + y0 + j) * 8] = hv[j][c];
+                    for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = vs[c];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int c = 0; c < 5; c++) pf[j][c] = nx[j][c];
             }
         }
     }
@@ -567,11 +580,9 @@ void blur_iteration(avd_ctx* ctx, int k, int np)
 {
     Workspace& ws = ctx->ws;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    launch1d(k_update_matrices, (int64_t)np * W * W, 256, ctx->stream, (const float*)ws.d_poly[k],
-             (const float*)ws.d_flow[k], ws.d_M, W, W, np);
     const int waves = np * NSTRIP;
-    hipLaunchKernelGGL(k_vd<W>, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, (const float*)ws.d_M, ws.d_vs,
-                       ws.d_vs0, np);
+    hipLaunchKernelGGL(k_uv<W>, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, (const float*)ws.d_poly[k],
+                       (const float*)ws.d_flow[k], ws.d_vs, ws.d_vs0, np);
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, ctx->stream, (const double*)ws.d_vs,
                        (const double*)ws.d_vs0, ws.d_flow[k], np);
 }

@@ -90,10 +90,9 @@ struct Workspace {
     HashParams hsh{};
     // farneback
     float* d_pyr[AVD_FB_LEVELS] = {};     // [n][hL*wL]
-    float* d_poly[AVD_FB_LEVELS] = {};    // [n][5][hL*wL]
+    float* d_poly[AVD_FB_LEVELS] = {};    // [n][hL*wL][5] interleaved polynomial coefficients
     float* d_tmp = nullptr;               // row-filtered scratch [n][320*320]
     float* d_flow[AVD_FB_LEVELS] = {};    // [n-1][2][hL*wL]  planar
-    float* d_M = nullptr;                 // [n-1][5][320*320] normal-equation planes
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)

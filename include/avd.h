@@ -113,7 +113,7 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 
 /* Test hook: copy an internal device buffer of the last call to host.
- * name: "area" uint8[n][1024]; "pyr<L>" float[n][hL][wL]; "poly<L>" float[n][5][hL][wL];
+ * name: "area" uint8[n][1024]; "pyr<L>" float[n][hL][wL]; "poly<L>" float[n][hL][wL][5];
  * "flow<L>" float[n-1][2][hL][wL] (planar, after the last iteration at level L).
  * Returns the number of bytes copied (>=0) or a negative status. */
 int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes);
