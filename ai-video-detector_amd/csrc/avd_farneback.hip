@@ -34,72 +34,71 @@ __device__ __forceinline__ int floor_f(float v) { int i = (int)v; return i - (i 
 // Gaussian pyramid level K (scale 2^-K): GaussianBlur(full-res, ksize, sigma) then the
 // INTER_LINEAR decimation, which at these exact power-of-two scales is the 2x2 mean
 // ((p00+p01)+(p10+p11))*0.25 of the two centre pixels.  Only the columns/rows the
-// decimation reads are filtered.
-//   row pass  : tmp[f][y][j]  j = 2*dx+{0,1} <-> source column (dx<<K)+off+{0,1}
-//   col pass  : I[f][dy][dx]
+// decimation reads are filtered.  One workgroup = TR output rows of one frame:
+//   source rows (uint8, reflect-101) -> LDS;  row pass (FMA chain, cv2's RowVec_32f order)
+//   -> LDS float [rows][NC];  column pass (SymmColumnVec_32f order) + 2x2 mean -> I[f][dy][dx].
 // ---------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void k_pyr_row(const uint8_t* __restrict__ small, int n,
-                                                const FbConsts* __restrict__ C, float* __restrict__ tmp)
-{
-    constexpr int WL = S >> K;
-    constexpr int NC = K == 0 ? S : 2 * WL;          // filtered columns per row
-    constexpr int OFF = K == 0 ? 0 : (1 << K) / 2 - 1;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (int64_t)n * S * NC) return;
-    const int j = (int)(gid % NC);
-    const int y = (int)((gid / NC) % S);
-    const int f = (int)(gid / ((int64_t)NC * S));
-    const int x = K == 0 ? j : ((j >> 1) << K) + OFF + (j & 1);
-    const uint8_t* row = small + (int64_t)f * AVD_NPIX + y * S;
-    const int ks = C->gksize[K];
-    const float* kx = C->gk[K];
-    float r;
-    if (ks == 3) {
-        const float l = (float)row[reflect101(x - 1, S)], c = (float)row[x], rr = (float)row[reflect101(x + 1, S)];
-        const float t = (l + rr) * kx[0];
-        r = __builtin_fmaf(c, kx[1], t);
-    } else {
-        const int half = ks >> 1;
-        r = 0.f;
-        for (int t = 0; t < ks; t++) r = __builtin_fmaf((float)row[reflect101(x - half + t, S)], kx[t], r);
-    }
-    tmp[gid] = r;
-}
-
-template <int K>
-__global__ __launch_bounds__(256) void k_pyr_col(const float* __restrict__ tmp, int n,
+__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ small, int n,
                                                 const FbConsts* __restrict__ C, float* __restrict__ I)
 {
     constexpr int WL = S >> K;
-    constexpr int NC = K == 0 ? S : 2 * WL;
+    constexpr int NC = K == 0 ? S : 2 * WL;              // filtered columns per row
     constexpr int OFF = K == 0 ? 0 : (1 << K) / 2 - 1;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (int64_t)n * WL * WL) return;
-    const int dx = (int)(gid % WL);
-    const int dy = (int)((gid / WL) % WL);
-    const int f = (int)(gid / (WL * WL));
-    const float* T = tmp + (int64_t)f * S * NC;
-    const int ks = C->gksize[K], half = ks >> 1;
-    const float* kc = C->gk[K] + half;
-    auto colf = [&](int y, int j) {
-        float s = __builtin_fmaf(T[y * NC + j], kc[0], 0.f);
-        for (int t = 1; t <= half; t++) {
-            const float a = T[reflect101(y + t, S) * NC + j], b = T[reflect101(y - t, S) * NC + j];
-            s = __builtin_fmaf(a + b, kc[t], s);
-        }
-        return s;
-    };
-    float out;
-    if (K == 0) {
-        out = colf(dy, dx);
-    } else {
-        const int y0 = (dy << K) + OFF;
-        const float p00 = colf(y0, 2 * dx), p01 = colf(y0, 2 * dx + 1);
-        const float p10 = colf(y0 + 1, 2 * dx), p11 = colf(y0 + 1, 2 * dx + 1);
-        out = ((p00 + p01) + (p10 + p11)) * 0.25f;
+    constexpr int TR = 8;                                // output rows per workgroup
+    constexpr int KS = K == 3 ? 19 : (K == 2 ? 9 : 3), HALF = KS / 2;
+    constexpr int SROWS = K == 0 ? TR + 2 * HALF : ((TR - 1) << K) + 2 + 2 * HALF;   // source rows needed
+    __shared__ __align__(16) uint8_t src[SROWS][S];
+    __shared__ float rowf[SROWS][NC];
+    const int tiles = WL / TR;
+    const int f = blockIdx.x / tiles, t = blockIdx.x - f * tiles;
+    const int tid = threadIdx.x;
+    const int dy0 = t * TR;
+    const int y_first = (K == 0 ? dy0 : (dy0 << K) + OFF) - HALF;        // first source row (may be < 0)
+    const uint8_t* img = small + (int64_t)f * AVD_NPIX;
+    for (int it = tid; it < SROWS * (S / 4); it += 256) {
+        const int r = it / (S / 4), c4 = it - r * (S / 4);
+        const int y = reflect101(y_first + r, S);
+        reinterpret_cast<unsigned*>(src[r])[c4] = reinterpret_cast<const unsigned*>(img + y * S)[c4];
     }
-    I[gid] = out;
+    __syncthreads();
+    const float* kx = C->gk[K];
+    for (int it = tid; it < SROWS * NC; it += 256) {
+        const int r = it / NC, j = it - r * NC;
+        const int x = K == 0 ? j : ((j >> 1) << K) + OFF + (j & 1);
+        const uint8_t* row = src[r];
+        float v;
+        if (KS == 3) {
+            const float l = (float)row[reflect101(x - 1, S)], c = (float)row[x], rr = (float)row[reflect101(x + 1, S)];
+            v = __builtin_fmaf(c, kx[1], (l + rr) * kx[0]);
+        } else {
+            v = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; k++) v = __builtin_fmaf((float)row[reflect101(x - HALF + k, S)], kx[k], v);
+        }
+        rowf[r][j] = v;
+    }
+    __syncthreads();
+    const float* kc = kx + HALF;
+    auto colf = [&](int rc, int j) {                     // rc = LDS row of the centre tap
+        float sacc = __builtin_fmaf(rowf[rc][j], kc[0], 0.f);
+#pragma unroll
+        for (int k = 1; k <= HALF; k++) sacc = __builtin_fmaf(rowf[rc + k][j] + rowf[rc - k][j], kc[k], sacc);
+        return sacc;
+    };
+    for (int it = tid; it < TR * WL; it += 256) {
+        const int dyl = it / WL, dx = it - dyl * WL;
+        float out;
+        if (K == 0) {
+            out = colf(dyl + HALF, dx);
+        } else {
+            const int rc = (dyl << K) + HALF;            // LDS row of source row (dy<<K)+OFF
+            const float p00 = colf(rc, 2 * dx), p01 = colf(rc, 2 * dx + 1);
+            const float p10 = colf(rc + 1, 2 * dx), p11 = colf(rc + 1, 2 * dx + 1);
+            out = ((p00 + p01) + (p10 + p11)) * 0.25f;
+        }
+        I[((int64_t)f * WL + dy0 + dyl) * WL + dx] = out;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -159,39 +158,45 @@ __global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, in
 // ---------------------------------------------------------------------------------------
 // Initial flow of a level: zeros at the coarsest level, otherwise the previous level's
 // flow resized x2 (INTER_LINEAR, float weights, cv2 edge rules) and multiplied by 2.
-// flow planes: [pair][2][h][w]
+// flow planes: [pair][2][h][w].  The destination is exactly 2x the source, so cv2's source
+// coordinate (d+0.5)*0.5-0.5 = d/2 - 0.25 is exact in float: s = floor, f in {0.75, 0.25};
+// horizontally the weights snap to the edge pixel (f = 0) when s falls outside [0, pw-1),
+// vertically the rows are clipped and the weights kept.  A lane produces 4 consecutive outputs.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev, int pw, int ph,
-                                                float* __restrict__ flow, int w, int h, int npairs)
+template <int W>
+__global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev, float* __restrict__ flow, int npairs)
 {
-    // destination is exactly 2x the source, so cv2's source coordinate (d+0.5)*0.5-0.5 = d/2 - 0.25
-    // is exact in float: s = floor, f in {0.75, 0.25}; horizontally the weights snap to the edge
-    // pixel (f = 0) when s falls outside [0, pw-1), vertically the rows are clipped, weights kept.
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (int64_t)npairs * 2 * w * h) return;
-    const int dx = (int)(gid % w);
-    const int dy = (int)((gid / w) % h);
-    const int64_t pc = gid / ((int64_t)w * h);             // pair*2 + channel
-    const float* src = prev + pc * pw * ph;
-    float fx = dx * 0.5f - 0.25f;
-    int sx = floor_f(fx);
-    fx -= sx;
-    if (sx < 0) { fx = 0; sx = 0; }
-    bool edge = false;                                      // dx >= xmax: value copied, no weights
-    if (sx + 1 >= pw) { edge = true; if (sx >= pw - 1) { fx = 0; sx = pw - 1; } }
+    constexpr int H = W, PW = W / 2, PH = H / 2, Q = W / 4;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npairs * 2 * H * Q) return;
+    const int q = gid % Q;
+    const int dy = (gid / Q) % H;
+    const int pc = gid / (Q * H);                          // pair*2 + channel
+    const float* src = prev + (int64_t)pc * PW * PH;
     float fy = dy * 0.5f - 0.25f;
-    int sy = floor_f(fy);
+    const int sy = floor_f(fy);
     fy -= sy;
-    const int y0 = clampi(sy, 0, ph - 1), y1 = clampi(sy + 1, 0, ph - 1);
-    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-    const int x1 = min(sx + 1, pw - 1);
-    float d0, d1;
-    if (edge) { d0 = src[y0 * pw + sx] * 1.f; d1 = src[y1 * pw + sx] * 1.f; }
-    else {
-        d0 = src[y0 * pw + sx] * a0 + src[y0 * pw + x1] * a1;
-        d1 = src[y1 * pw + sx] * a0 + src[y1 * pw + x1] * a1;
+    const float* r0 = src + clampi(sy, 0, PH - 1) * PW;
+    const float* r1 = src + clampi(sy + 1, 0, PH - 1) * PW;
+    const float b0 = 1.f - fy, b1 = fy;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = q * 4 + i;
+        float fx = dx * 0.5f - 0.25f;
+        int sx = floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        bool edge = false;                                  // dx >= xmax: value copied, no weights
+        if (sx + 1 >= PW) { edge = true; if (sx >= PW - 1) { fx = 0; sx = PW - 1; } }
+        const int x1 = min(sx + 1, PW - 1);
+        const float a0 = 1.f - fx, a1 = fx;
+        float d0, d1;
+        if (edge) { d0 = r0[sx] * 1.f; d1 = r1[sx] * 1.f; }
+        else { d0 = r0[sx] * a0 + r0[x1] * a1; d1 = r1[sx] * a0 + r1[x1] * a1; }
+        o[i] = (d0 * b0 + d1 * b1) * 2.f;
     }
-    flow[gid] = (d0 * b0 + d1 * b1) * 2.f;
+    *reinterpret_cast<float4*>(flow + ((int64_t)pc * H + dy) * W + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W), NYB = d16_nyb(H);
     constexpr int plane = W * H;
-    __shared__ double xch[4][5][64];
+    __shared__ double xch[4][2][5][64];
     const int wv = threadIdx.x >> 6;
     const int wid = blockIdx.x * 4 + wv;
     if (wid >= npairs * NSTRIP) return;
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
     const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
     const unsigned dbase = ((unsigned)p * NYB * 5 * XCH + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
     const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
-    double (*xw)[64] = xch[wv];
+    double (*xw)[5][64] = xch[wv];
     const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
 
     float ring[16][5];                                  // rows y-8 .. y+7, slot = row & 15
@@ -350,38 +355,63 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
     ne_gather(R, r1base, in[0], x, m, W, H, plane, g[0]);
     ne_gather(R, r1base, in[1], x, min(m + 1, H - 1), W, H, plane, g[1]);
 
+    // Two rows per step: their normal equations, LDS exchange and stores are independent, only the
+    // five double adds per row chain; pairing the rows inside one basic block lets the scheduler hide
+    // one row's latencies (LDS round trip, dependent f64 adds) behind the other's arithmetic.
     for (int yb = 0; yb < H; yb += 16) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int y = yb + j;
-            if (y < H) {                                 // only false in the tail block of H = 40
-                const int r = min(y + m, H - 1);         // entering row (clamped: its value is M(H-1) again)
-                float a[5];
-                ne_finish(in[j & 3], g[j & 1], x, r, W, H, a);
-                // refill the two slots just consumed: gathers of row r+2, inputs of row r+4
-                ne_gather(R, r1base, in[(j + 2) & 3], x, min(r + 2, H - 1), W, H, plane, g[j & 1]);
-                ne_load(R, flow, r0base, flbase, x, min(r + 4, H - 1), W, plane, in[j & 3]);
-                double dv[5];
+        for (int jj = 0; jj < 8; jj++) {
+            const int j0 = 2 * jj, j1 = j0 + 1;
+            const int y0 = yb + j0, y1 = y0 + 1;
+            if (y0 < H) {                                // H is even; only false in the tail block of H = 40
+                const int ra = min(y0 + m, H - 1), rb = min(y1 + m, H - 1);   // entering rows (clamped)
+                float a0[5], a1[5];
+                ne_finish(in[j0 & 3], g[j0 & 1], x, ra, W, H, a0);
+                ne_finish(in[j1 & 3], g[j1 & 1], x, rb, W, H, a1);
+                // refill the slots just consumed: gathers of rows r+2, inputs of rows r+4
+                ne_gather(R, r1base, in[(j0 + 2) & 3], x, min(ra + 2, H - 1), W, H, plane, g[j0 & 1]);
+                ne_gather(R, r1base, in[(j1 + 2) & 3], x, min(rb + 2, H - 1), W, H, plane, g[j1 & 1]);
+                ne_load(R, flow, r0base, flbase, x, min(ra + 4, H - 1), W, plane, in[j0 & 3]);
+                ne_load(R, flow, r0base, flbase, x, min(rb + 4, H - 1), W, plane, in[j1 & 3]);
+                double h0[5], h1[5];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    const float b = y >= m + 1 ? ring[(j + 8) & 15][c] : ring[0][c];
-                    ring[(j + m) & 15][c] = a[c];
-                    vs[c] += (double)(a[c] - b);
-                    xw[c][lane] = vs[c];
+                    const float b0 = y0 >= m + 1 ? ring[(j0 + 8) & 15][c] : ring[0][c];
+                    ring[(j0 + m) & 15][c] = a0[c];
+                    vs[c] += (double)(a0[c] - b0);
+                    h0[c] = vs[c];
+                    xw[0][c][lane] = vs[c];
+                    const float b1 = y1 >= m + 1 ? ring[(j1 + 8) & 15][c] : ring[0][c];
+                    ring[(j1 + m) & 15][c] = a1[c];
+                    vs[c] += (double)(a1[c] - b1);
+                    h1[c] = vs[c];
+                    xw[1][c][lane] = vs[c];
                 }
                 __builtin_amdgcn_wave_barrier();
+                double d0[5], d1[5];
 #pragma unroll
-                for (int c = 0; c < 5; c++) dv[c] = xw[c][lhi] - xw[c][llo];
+                for (int c = 0; c < 5; c++) {
+                    d0[c] = xw[0][c][lhi] - xw[0][c][llo];
+                    d1[c] = xw[1][c][lhi] - xw[1][c][llo];
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (writer) {
-                    const unsigned trow = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8;
-                    const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
+                    const unsigned sw0 = (unsigned)((x & 7) ^ (y0 & 7)) - (unsigned)(x & 7);   // swizzled slot - plain slot
+                    const unsigned sw1 = (unsigned)((x & 7) ^ (y1 & 7)) - (unsigned)(x & 7);
+                    const unsigned t0 = dbase + ((unsigned)(y0 >> 6) * 5 * XCH) * 512u + (y0 & 63) * 8 + sw0;
+                    const unsigned t1 = dbase + ((unsigned)(y1 >> 6) * 5 * XCH) * 512u + (y1 & 63) * 8 + sw1;
 #pragma unroll
-                    for (int c = 0; c < 5; c++) D16[trow + sw + (unsigned)c * XCH * 512u] = dv[c];
+                    for (int c = 0; c < 5; c++) {
+                        D16[t0 + (unsigned)c * XCH * 512u] = d0[c];
+                        D16[t1 + (unsigned)c * XCH * 512u] = d1[c];
+                    }
                 }
                 if (head) {
 #pragma unroll
-                    for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = vs[c];
+                    for (int c = 0; c < 5; c++) {
+                        VS0[vbase + (unsigned)((c * H + y0) * 8)] = h0[c];
+                        VS0[vbase + (unsigned)((c * H + y1) * 8)] = h1[c];
+                    }
                 }
             }
         }
@@ -566,10 +596,8 @@ void pyramid_level(avd_ctx* ctx, const uint8_t* d_small, int n)
 {
     Workspace& ws = ctx->ws;
     constexpr int WL = S >> K;
-    constexpr int NC = K == 0 ? S : 2 * WL;
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
-    launch1d(k_pyr_row<K>, (int64_t)n * S * NC, 256, ctx->stream, d_small, n, C, ws.d_tmp);
-    launch1d(k_pyr_col<K>, (int64_t)n * WL * WL, 256, ctx->stream, (const float*)ws.d_tmp, n, C, ws.d_pyr[K]);
+    hipLaunchKernelGGL(k_pyramid<K>, dim3(n * (WL / 8)), dim3(256), 0, ctx->stream, d_small, n, C, ws.d_pyr[K]);
     hipLaunchKernelGGL(k_polyexp, dim3(n * WL), dim3(320), 0, ctx->stream, (const float*)ws.d_pyr[K], WL, WL, C,
                        ws.d_poly[K]);
 }
@@ -602,11 +630,15 @@ int launch_farneback(avd_ctx* ctx, const uint8_t* d_small, int n)
     for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
         const int w = S >> k, h = S >> k;
         const int64_t plane = (int64_t)w * h;
-        if (k == AVD_FB_LEVELS - 1)
+        if (k == AVD_FB_LEVELS - 1) {
             HIP_TRY(ctx, hipMemsetAsync(ws.d_flow[k], 0, sizeof(float) * 2 * plane * np, ctx->stream));
-        else
-            launch1d(k_flow_up, (int64_t)np * 2 * plane, 256, ctx->stream, (const float*)ws.d_flow[k + 1],
-                     w / 2, h / 2, ws.d_flow[k], w, h, np);
+        } else {
+            const int items = np * 2 * h * (w / 4);
+            const float* prev = ws.d_flow[k + 1];
+            if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, ctx->stream, prev, ws.d_flow[k], np);
+            else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, ctx->stream, prev, ws.d_flow[k], np);
+            else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, ctx->stream, prev, ws.d_flow[k], np);
+        }
         for (int it = 0; it < 3; it++) {
             switch (k) {
             case 3: blur_iteration<S / 8>(ctx, k, np); break;
