@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) path, reported apart")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,26 +79,31 @@ def main():
     from avd_hip.timeline import records_to_result
     avd_hip.load()                                  # fail loudly before anything else if the .so is missing
     import torch
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("AVD_BENCH_DEVICE", local_rank))      # rehearsal: several ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1
     if use_dist:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            tdist.init_process_group("nccl", device_id=dev)
+        else:
+            tdist.init_process_group("gloo")
+    gather_dev = dev if args.backend == "nccl" else None
 
     n, h, w = args.frames, args.height, args.width
     meta = {"width": w, "height": h, "fps": 30.0, "duration": n / 2.0}
     clip = synth.make_clip(n, h, w, seed=args.seed + rank)          # synthetic, SURVEY.md 8(d) recipe
     frames = torch.from_numpy(clip).to(dev)                          # resident in HBM before timing
-    ctx = avd_hip.Context(local_rank)
+    ctx = avd_hip.Context(dev_index)
     ctx.set_profiling(True)
     rec = np.zeros(n, avd_hip.RECORD_DTYPE)
 
     def step():
         ctx.analyze_frames_async(frames, rec)
         ctx.synchronize()
-        allrec = avd_dist.gather_fixed(rec, device=dev) if use_dist else rec
+        allrec = avd_dist.gather_fixed(rec, device=gather_dev) if use_dist else rec
         # scalar tail (video.py:54-83) for this rank's clip; other clips' records are now local too
         return records_to_result(allrec[rank * n:(rank + 1) * n], h * w, w, h, meta["fps"], meta["duration"])
 
@@ -116,7 +123,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage /= max(args.steps, 1)
@@ -126,6 +133,11 @@ def main():
         fps_total = world * n * args.steps / elapsed
         pre_ms = float(stage[0])
         alg = algorithmic_bytes_per_frame(h, w) * n
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this kernel
+        pmc_file = os.path.join(ROOT, "profiles", "r01_preprocess_pmc.json")
+        if os.path.exists(pmc_file) and (n, h, w) == (120, 1080, 1920):
+            with open(pmc_file) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
         achieved = alg / (pre_ms * 1e-3) / 1e9 if pre_ms > 0 else 0.0
         out = {
             "metric": "sampled frames/sec analysed (1080p30 60 s clip, 2 fps sampling)",
@@ -137,10 +149,10 @@ def main():
                        "frames_per_clip": n, "height": h, "width": w, "clips_per_step": world,
                        "sec_per_video": round(ms_per_step / 1e3, 6),
                        "decoded_frame_equivalent_fps": round(fps_total * 15, 1),
-                       "parallelism": f"clip-parallel x{world}, one all-gather of 32 B/frame records" if world > 1 else "single GPU"},
+                       "parallelism": f"clip-parallel x{world}, one all-gather ({args.backend}) of 32 B/frame records" if world > 1 else "single GPU"},
             "roofline": {"kernel": "k_preprocess (fused BGR->gray, INTER_AREA partials, INTER_LINEAR 320x320, Laplacian moments)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(pre_ms, 4),
                          "share_of_step": round(pre_ms / ms_per_step, 4)},
             "stages_ms": {"preprocess": round(float(stage[0]), 4), "hash_hamming_records": round(float(stage[1]), 4),
