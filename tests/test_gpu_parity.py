@@ -109,6 +109,23 @@ def test_analyze_frames_end_to_end(ctx, oracle):
     assert got["summary"]["dup_density"] > 0          # duplicates were detected
 
 
+def test_long_clip_crosses_farneback_chunk_boundary(ctx, oracle):
+    """The Farneback workspace holds 128 pairs; longer clips are processed in chunks that overlap by
+    one frame.  131 frames -> pairs 127|128 straddle the boundary: records there must equal the oracle."""
+    base = synth.make_clip(8, 64, 96, seed=31, dup_every=0)
+    idx = np.arange(131) % 8
+    clip = base[idx]                                        # cheap long clip (8 distinct frames cycled)
+    rec = ctx.analyze_frames(clip)
+    small = np.stack([oracle.resize_linear(oracle.bgr2gray(f), 320, 320) for f in base])
+    for p in (0, 126, 127, 128, 129):
+        a, b = idx[p], idx[p + 1]
+        m, v = oracle.flow_stats(oracle.farneback(small[a], small[b]))
+        assert rec["flow_mean"][p + 1] == m and rec["flow_var"][p + 1] == v, p
+    # the cycle repeats every 8 frames: equal pairs must give equal records on both sides of the boundary
+    assert rec["flow_mean"][120 + 1] == rec["flow_mean"][128 + 1] and rec["flow_var"][121 + 1] == rec["flow_var"][129 + 1]
+    assert rec["ham"][0] == -1 and np.all(rec["ham"][1:] >= 0)
+
+
 def test_streaming_chunks_equal_one_shot(ctx):
     import avd_hip
     clip = synth.make_clip(9, 180, 320, seed=2)
