@@ -584,6 +584,39 @@ __global__ void k_flow_interleave(const float* __restrict__ flow, float* __restr
     out[gid * 2 + 1] = flow[(p * 2 + 1) * AVD_NPIX + i];
 }
 
+// A segment = a run of consecutive pairs processed on one stream, with its own slice of the workspace
+// (frames [frame_off, ...) and pairs [pair_off, ...) of the chunk), so that two segments of a clip can
+// be in flight on two streams: the small-level launches of one fill the latency gaps of the other.
+struct Seg {
+    hipStream_t stream;
+    const float* pyr[AVD_FB_LEVELS];
+    float* pyr_w[AVD_FB_LEVELS];
+    float* poly[AVD_FB_LEVELS];
+    float* flow[AVD_FB_LEVELS];
+    double *vs, *vs0;
+    float *stats, *part, *flow_il;
+};
+
+static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_off)
+{
+    Workspace& ws = ctx->ws;
+    Seg g{};
+    g.stream = stream;
+    for (int k = 0; k < AVD_FB_LEVELS; k++) {
+        const size_t plane = (size_t)(S >> k) * (S >> k);
+        g.pyr_w[k] = ws.d_pyr[k] + (size_t)frame_off * plane;
+        g.pyr[k] = g.pyr_w[k];
+        g.poly[k] = ws.d_poly[k] + (size_t)frame_off * 5 * plane;
+        g.flow[k] = ws.d_flow[k] + (size_t)pair_off * 2 * plane;
+    }
+    g.vs = ws.d_vs + (size_t)pair_off * 5 * AVD_NPIX;
+    g.vs0 = ws.d_vs0 + (size_t)pair_off * 5 * S * 8;
+    g.stats = ws.d_stats + (size_t)pair_off * 2;
+    g.part = ws.d_part + (size_t)pair_off * 2 * 16;
+    g.flow_il = ws.d_flow_il ? ws.d_flow_il + (size_t)pair_off * AVD_NPIX * 2 : nullptr;
+    return g;
+}
+
 template <typename... A>
 inline void launch1d(void (*k)(A...), int64_t items, int block, hipStream_t s, A... args)
 {
@@ -592,59 +625,57 @@ inline void launch1d(void (*k)(A...), int64_t items, int block, hipStream_t s, A
 }
 
 template <int K>
-void pyramid_level(avd_ctx* ctx, const uint8_t* d_small, int n)
+void pyramid_level(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int n)
 {
-    Workspace& ws = ctx->ws;
     constexpr int WL = S >> K;
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
-    hipLaunchKernelGGL(k_pyramid<K>, dim3(n * (WL / 8)), dim3(256), 0, ctx->stream, d_small, n, C, ws.d_pyr[K]);
-    hipLaunchKernelGGL(k_polyexp, dim3(n * WL), dim3(320), 0, ctx->stream, (const float*)ws.d_pyr[K], WL, WL, C,
-                       ws.d_poly[K]);
+    hipLaunchKernelGGL(k_pyramid<K>, dim3(n * (WL / 8)), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[K]);
+    hipLaunchKernelGGL(k_polyexp, dim3(n * WL), dim3(320), 0, g.stream, g.pyr[K], WL, WL, C, g.poly[K]);
 }
 
 // one FarnebackUpdateFlow_Blur iteration at level k: matrices from the current flow, box sums, solve
 template <int W>
-void blur_iteration(avd_ctx* ctx, int k, int np)
+void blur_iteration(const Seg& g, int k, int np)
 {
-    Workspace& ws = ctx->ws;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
     const int waves = np * NSTRIP;
-    hipLaunchKernelGGL(k_uv<W>, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, (const float*)ws.d_poly[k],
-                       (const float*)ws.d_flow[k], ws.d_vs, ws.d_vs0, np);
-    hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, ctx->stream, (const double*)ws.d_vs,
-                       (const double*)ws.d_vs0, ws.d_flow[k], np);
+    hipLaunchKernelGGL(k_uv<W>, dim3((waves + 3) / 4), dim3(256), 0, g.stream, (const float*)g.poly[k],
+                       (const float*)g.flow[k], g.vs, g.vs0, np);
+    hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,
+                       (const double*)g.vs0, g.flow[k], np);
 }
 
 }  // namespace
 
-// All pairs (f, f+1), f in [0, n-1), of n resident 320x320 frames.
-int launch_farneback(avd_ctx* ctx, const uint8_t* d_small, int n)
+// All pairs (f, f+1), f in [0, n-1), of n resident 320x320 frames, on one stream, using the workspace
+// slice (frame_off, pair_off) of the current chunk.
+int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off)
 {
     if (n < 2) return 0;
-    Workspace& ws = ctx->ws;
+    const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     const int np = n - 1;
-    pyramid_level<3>(ctx, d_small, n);
-    pyramid_level<2>(ctx, d_small, n);
-    pyramid_level<1>(ctx, d_small, n);
-    pyramid_level<0>(ctx, d_small, n);
+    pyramid_level<3>(ctx, g, d_small, n);
+    pyramid_level<2>(ctx, g, d_small, n);
+    pyramid_level<1>(ctx, g, d_small, n);
+    pyramid_level<0>(ctx, g, d_small, n);
     for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
         const int w = S >> k, h = S >> k;
         const int64_t plane = (int64_t)w * h;
         if (k == AVD_FB_LEVELS - 1) {
-            HIP_TRY(ctx, hipMemsetAsync(ws.d_flow[k], 0, sizeof(float) * 2 * plane * np, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
         } else {
             const int items = np * 2 * h * (w / 4);
-            const float* prev = ws.d_flow[k + 1];
-            if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, ctx->stream, prev, ws.d_flow[k], np);
-            else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, ctx->stream, prev, ws.d_flow[k], np);
-            else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, ctx->stream, prev, ws.d_flow[k], np);
+            const float* prev = g.flow[k + 1];
+            if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
+            else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
+            else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
         }
         for (int it = 0; it < 3; it++) {
             switch (k) {
-            case 3: blur_iteration<S / 8>(ctx, k, np); break;
-            case 2: blur_iteration<S / 4>(ctx, k, np); break;
-            case 1: blur_iteration<S / 2>(ctx, k, np); break;
-            default: blur_iteration<S>(ctx, k, np); break;
+            case 3: blur_iteration<S / 8>(g, k, np); break;
+            case 2: blur_iteration<S / 4>(g, k, np); break;
+            case 1: blur_iteration<S / 2>(g, k, np); break;
+            default: blur_iteration<S>(g, k, np); break;
             }
         }
     }
@@ -652,18 +683,17 @@ int launch_farneback(avd_ctx* ctx, const uint8_t* d_small, int n)
     return 0;
 }
 
-int launch_flow_stats(avd_ctx* ctx, int n)
+int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off)
 {
     if (n < 2) return 0;
-    Workspace& ws = ctx->ws;
+    const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     const int np = n - 1;
-    const float* fl = ws.d_flow[0];
-    hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, ctx->stream, fl, ws.d_part);
-    hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, ctx->stream, fl, ws.d_part);
-    hipLaunchKernelGGL(k_stats_final, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, (const float*)ws.d_part,
-                       ws.d_stats, np);
-    if (ws.d_flow_il)
-        launch1d(k_flow_interleave, (int64_t)np * AVD_NPIX, 256, ctx->stream, fl, ws.d_flow_il, (int64_t)np * AVD_NPIX);
+    const float* fl = g.flow[0];
+    hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
+    hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
+    hipLaunchKernelGGL(k_stats_final, dim3((np + 63) / 64), dim3(64), 0, stream, (const float*)g.part, g.stats, np);
+    if (g.flow_il)
+        launch1d(k_flow_interleave, (int64_t)np * AVD_NPIX, 256, stream, fl, g.flow_il, (int64_t)np * AVD_NPIX);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -106,6 +106,8 @@ struct avd_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // second Farneback segment of a clip runs here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t stage_ev[5] = {};
     int profiling = 0;
@@ -123,5 +125,5 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n);
 int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
                       int64_t row_stride, int64_t frame_stride);
 int launch_hash(avd_ctx* ctx, int n);
-int launch_farneback(avd_ctx* ctx, const uint8_t* d_small, int n);
-int launch_flow_stats(avd_ctx* ctx, int n);
+int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off);
+int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);
