@@ -37,6 +37,32 @@ def test_preprocess_bit_exact(ctx, oracle, n, h, w):
     assert np.array_equal(hsh, o_hsh)
 
 
+def test_preprocess_random_geometries(ctx, oracle):
+    """Seeded sweep over arbitrary (mostly odd) frame sizes: general INTER_AREA tables with partial cells,
+    scalar load path, last band of any height."""
+    rng = np.random.default_rng(99)
+    for _ in range(12):
+        h, w = int(rng.integers(32, 400)), int(rng.integers(32, 700))
+        frames = synth.random_frames(2, h, w, seed=h * 1000 + w)
+        got = ctx.preprocess_bgr(frames)
+        want = oracle.preprocess_bgr(frames)
+        for name, x, y in zip(("small", "hash", "lap_sum", "lap_sumsq"), got, want):
+            assert np.array_equal(x, y), (h, w, name)
+
+
+def test_preprocess_extreme_values(ctx, oracle):
+    """All-0 / all-255 / checkerboard frames: saturating sums, maximal Laplacian magnitudes (|lap| = 1020)."""
+    h, w = 128, 192
+    chk = ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8)
+    frames = np.stack([np.zeros((h, w, 3), np.uint8), np.full((h, w, 3), 255, np.uint8),
+                       np.repeat(chk[..., None], 3, axis=2), np.repeat((255 - chk)[..., None], 3, axis=2)])
+    got = ctx.preprocess_bgr(frames)
+    want = oracle.preprocess_bgr(frames)
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    assert got[3][2] == 1020 * 1020 * (h * w) and got[2][2] == 0        # checkerboard: |lap| = 1020 at every pixel
+
+
 def test_preprocess_smooth_and_strided(ctx, oracle):
     clip = synth.make_clip(4, 270, 480, seed=3)
     # non-contiguous view: row stride larger than w*3 and a frame stride with a gap
@@ -84,6 +110,28 @@ def test_farneback_stages_bit_exact(ctx, oracle):
         assert np.array_equal(flow[p], o_flow), f"pair {p}: max |d| = {np.abs(flow[p] - o_flow).max()}"
         m, v = oracle.flow_stats(o_flow)
         assert fm[p] == m and fv[p] == v
+
+
+def test_farneback_hard_inputs_bit_exact(ctx, oracle):
+    """Content that drives the warp out of the image, saturates, or is flat: white noise (large
+    erratic flow -> the out-of-range branch of UpdateMatrices), constant, half-saturated step edges,
+    and a frame pair with a big global shift."""
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (2, 320, 320), dtype=np.uint8)
+    const = np.full((320, 320), 200, np.uint8)
+    step = np.zeros((320, 320), np.uint8)
+    step[:, 160:] = 255
+    step2 = np.zeros((320, 320), np.uint8)
+    step2[:, 190:] = 255                                   # 30 px jump of a saturated edge
+    ramp = (np.add.outer(np.arange(320), np.arange(320)) % 256).astype(np.uint8)
+    frames = np.stack([noise[0], noise[1], const, step, step2, ramp, np.roll(ramp, 25, axis=1), const])
+    fm, fv, flow = ctx.farneback_pairs(frames, want_flow=True)
+    for p in range(len(frames) - 1):
+        o_flow = oracle.farneback(frames[p], frames[p + 1])
+        assert np.array_equal(flow[p], o_flow), f"pair {p}: {np.count_nonzero(flow[p] != o_flow)} values differ"
+        m, v = oracle.flow_stats(o_flow)
+        assert fm[p] == m and fv[p] == v, p
+    assert np.isfinite(flow).all()
 
 
 def test_flow_stats_match_numpy(ctx, oracle):
