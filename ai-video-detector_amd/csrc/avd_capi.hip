@@ -28,13 +28,14 @@ int rows_per_band_for(int w)
 {
     // LDS tile = (rows+2) * pitch bytes, kept under 48 KiB so that >= 3 workgroups fit a CU
     const int pitch = ((w + 32 + 15) / 16) * 16;
-    int r = (48 * 1024) / pitch - 2;
+    const bool big = [] { const char* e = std::getenv("AVD_PRE_NT"); return e && std::atoi(e) == 512; }();
+    int r = ((big ? 72 : 48) * 1024) / pitch - 2;
     int cap = 14;                      // 16 tile rows + LDS tables = 37 KiB at 1080p: 4 workgroups per CU
     if (w % 16 == 0 && w / 16 <= 256) {
         // aligned fast path: a lane holds at most 9 row chunks (3 x 16 B each) in registers, so the
         // tile may have at most 9 * (rows covered per pass) rows -- 7-row bands at 4K
-        const int rpp = 256 / (w / 16);
-        cap = std::min(cap, 9 * rpp - 2);
+        const int rpp = (big ? 512 : 256) / (w / 16);
+        cap = std::min(big ? 30 : cap, 9 * rpp - 2);
     }
     if (const char* e = std::getenv("AVD_ROWS_PER_BAND")) cap = std::max(1, std::atoi(e));   // tuning knob
     r = std::min(r, cap);

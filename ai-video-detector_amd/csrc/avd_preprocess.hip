@@ -343,8 +343,8 @@ __global__ __launch_bounds__(kThreads) void k_preprocess(const uint8_t* __restri
 // the first conversion, so a workgroup has its whole band in flight at once; conversions start as
 // the words arrive (vmcnt counts down in issue order).  The lanes that convert the first / last
 // chunk also write the reflected halo bytes, which saves a barrier.
-template <int NI>
-__global__ __launch_bounds__(kThreads, 4) void k_preprocess_vec(const uint8_t* __restrict__ bgr, int n,
+template <int NI, int NT>
+__global__ __launch_bounds__(NT, 4) void k_preprocess_vec(const uint8_t* __restrict__ bgr, int n,
                                                                PreParams P, uint8_t* __restrict__ small,
                                                                float* __restrict__ rowbuf,
                                                                long long* __restrict__ lap_part)
@@ -360,10 +360,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_preprocess_vec(const uint8_t* _
     const int trows = rows + 2;
     const int tid = threadIdx.x;
     const int chunks = w >> 4;
-    const int rpp = kThreads / chunks;                     // tile rows covered per pass of the workgroup
+    const int rpp = NT / chunks;                     // tile rows covered per pass of the workgroup
     const int rsub = tid / chunks, c = tid - rsub * chunks;
     LdsTabs* lt = reinterpret_cast<LdsTabs*>(tile + (P.rows_per_band + 2) * pitch);
-    fill_lds_tabs<kThreads>(lt, P, tid);
+    fill_lds_tabs<NT>(lt, P, tid);
     if (rsub < rpp) {
         const uint8_t* col = bgr + (int64_t)f * P.frame_stride + c * 48;
         uint4 q[NI][3];
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_preprocess_vec(const uint8_t* _
         }
     }
     __syncthreads();
-    const Moments m = band_phases<kThreads, true>(tile, lt, P, f, band, r0, rows, tid, small, rowbuf);
+    const Moments m = band_phases<NT, true>(tile, lt, P, f, band, r0, rows, tid, small, rowbuf);
     // per-wave partial moments, summed per frame in k_hash (atomics on the 16 B/frame accumulators
     // serialise in L2: 65 k same-line atomics cost ~50 us per launch)
     const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
@@ -490,21 +490,31 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
     const bool vec = (w % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(d_bgr) % 16 == 0);
     const int chunks = w >> 4;
-    const int ni = (vec && chunks <= kThreads) ? (P.rows_per_band + 2 + kThreads / chunks - 1) / (kThreads / chunks) : 0;
     const size_t lds1 = (size_t)(P.rows_per_band + 2) * P.pitch;
     const size_t lds_vec = lds1 + sizeof(LdsTabs);
     const int grid1 = ((total + 7) / 8) * 8;
+    static const int nt_pref = [] { const char* e = std::getenv("AVD_PRE_NT"); return e ? std::atoi(e) : 256; }();
+    const int nt = (nt_pref == 512 && chunks <= 512) ? 512 : 256;
+    const int ni_nt = (vec && chunks <= nt) ? (P.rows_per_band + 2 + nt / chunks - 1) / (nt / chunks) : 0;
     ws.lap_waves = kThreads / 64;
-    if (ni > 0 && ni <= 9) {
-#define AVD_VEC_CASE(N) hipLaunchKernelGGL(k_preprocess_vec<N>, dim3(grid1), dim3(kThreads), lds_vec, ctx->stream, d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part)
-        switch (ni) {
+    if (ni_nt > 0 && ni_nt <= 9) {
+        ws.lap_waves = nt / 64;
+#define AVD_VEC_CASE(N)                                                                                              \
+    do {                                                                                                             \
+        if (nt == 512)                                                                                               \
+            hipLaunchKernelGGL((k_preprocess_vec<N, 512>), dim3(grid1), dim3(512), lds_vec, ctx->stream, d_bgr, n, P, \
+                               ws.d_small, ws.d_rowbuf, ws.d_lap_part);                                              \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_preprocess_vec<N, 256>), dim3(grid1), dim3(256), lds_vec, ctx->stream, d_bgr, n, P, \
+                               ws.d_small, ws.d_rowbuf, ws.d_lap_part);                                              \
+    } while (0)
+        switch (ni_nt) {
         case 1: case 2: case 3: AVD_VEC_CASE(3); break;
         case 4: AVD_VEC_CASE(4); break;
         case 5: AVD_VEC_CASE(5); break;
         case 6: AVD_VEC_CASE(6); break;
         case 7: AVD_VEC_CASE(7); break;
         case 8: AVD_VEC_CASE(8); break;
-        case 9: AVD_VEC_CASE(9); break;
         default: AVD_VEC_CASE(9); break;
         }
 #undef AVD_VEC_CASE

@@ -56,3 +56,39 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
         rec["ham"][0] = -1
         assert np.array_equal(rec, whole)
     assert np.array_equal(np.load(tmp_path / "tl0.npy"), np.load(tmp_path / "tl1.npy"))
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "ai-video-detector_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import avd_hip
+    from avd_hip import dist as avd_dist, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clip = synth.make_clip(10, 96, 160, seed=23, dup_every=4)        # same clip on every rank
+        with avd_hip.Context(0) as ctx:                                  # both ranks share the one GPU of the test box
+            local = avd_dist.analyze_shard(ctx.analyze_frames, clip, rank, world)   # shard + one-frame halo
+        allrec = avd_dist.all_gather_records(local)
+        np.save(os.path.join(out_dir, f"gpu_rec{rank}.npy"), allrec)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_frame_sharded_hip_path_two_ranks(tmp_path, ctx):
+    """One clip sharded over two ranks (each analyses its frame range + a one-frame halo through the
+    HIP path), records all-gathered: identical to the single-context result."""
+    from avd_hip import synth
+    world, port = 2, _free_port()
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    clip = synth.make_clip(10, 96, 160, seed=23, dup_every=4)
+    whole = ctx.analyze_frames(clip)
+    for r in range(world):
+        rec = np.load(tmp_path / f"gpu_rec{r}.npy")
+        assert np.array_equal(rec, whole)
