@@ -60,8 +60,7 @@ void free_ws(Workspace& ws)
     F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap); F(ws.d_lap_part);
     F(ws.d_tables);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
-    F(ws.d_tmp); F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
-    if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
+    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
     ws = Workspace{};
 }
 
@@ -145,8 +144,6 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
         if (int e = dev_alloc(ctx, ws.d_lap, (size_t)cap * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_lap_part, (size_t)cap * ws.pre.nbands * 8 * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_rec, (size_t)cap)) return e;
-        if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
-        HIP_TRY(ctx, hipHostMalloc((void**)&ws.h_rec, sizeof(avd_frame_record) * cap, hipHostMallocDefault));
         ws.cap_n = cap; ws.h = h; ws.w = w;
     }
     return 0;
@@ -164,7 +161,6 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
         if (int e = dev_alloc(ctx, ws.d_poly[k], nf * 5 * plane)) return e;
         if (int e = dev_alloc(ctx, ws.d_flow[k], np * 2 * plane)) return e;
     }
-    if (int e = dev_alloc(ctx, ws.d_tmp, nf * AVD_NPIX)) return e;
     if (int e = dev_alloc(ctx, ws.d_vs0, np * 5 * AVD_SMALL * 8)) return e;
     if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
     if (int e = dev_alloc(ctx, ws.d_part, np * 2 * 16)) return e;

@@ -10,10 +10,12 @@
 //     shared by the two pairs a frame belongs to (cv2 recomputes it per pair);
 //   * all pairs of a clip advance through level/iteration in lock step, one launch per
 //     stage, so every launch has >= 10^5 independent work items;
-//   * planar (structure-of-arrays) R / M / flow planes so that neighbouring lanes touch
-//     neighbouring addresses (cv2 interleaves 5 channels per pixel).
-// Not GEMM-shaped (11/19-tap separable stencils, 15x15 box sums, per-pixel 2x2 solves):
-// VALU + cache bound, MFMA is not applicable (DESIGN.md "Farneback").
+//   * the 5-channel normal-equation image M of cv2 never exists in memory (k_uv), the only large
+//     intermediate is D = vsum(x+7) - vsum(x-8) in double, stored in LDS-stageable tiles;
+//   * layouts follow the access pattern of their consumer: R interleaved [y][x][5] (bilinear gathers
+//     read 10 consecutive floats), flow planar, D tiled + XOR-swizzled.
+// Not GEMM-shaped (11/19-tap separable stencils, 15x15 box sums, per-pixel 2x2 solves): HBM-traffic
+// bound by the exact re-enactment of cv2's running double sums; MFMA is not applicable.
 #include "avd_internal.h"
 
 #pragma clang fp contract(off)
@@ -204,27 +206,27 @@ __global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev,
 // rounds at every slide, so the value at (y,x) depends on the whole column / row prefix; the
 // chains are reproduced literally, one lane per chain, in two kernels:
 //
-// k_vd  (lanes along x, sequential in y): vertical running sums vsum in double.  The
-//   horizontal pass only ever needs D(x) = vsum(x+7) - vsum(x-8), which is formed here with
-//   wave shuffles (a wave owns 48 output columns + 8/8 halo lanes, clamped at the edge = cv2's
-//   replicate border) and is the only thing written (+ columns 0..6 of vsum for the row init).
-//   D is stored in 64-row x 8-column tiles (4 KiB, one tile per channel), the unit k_hscan
-//   stages through LDS; inside a tile the 8 doubles of a row are XOR-swizzled by (row & 7)
-//   so that lanes reading "their" row spread over the LDS banks.  8 consecutive lanes write
-//   one 64-byte half line.
+// k_uv  (lanes along x, sequential in y; defined further down): FarnebackUpdateMatrices fused with the
+//   vertical running sums vsum in double.  The horizontal pass only ever needs
+//   D(x) = vsum(x+7) - vsum(x-8), which is formed there (a wave owns 48 output columns + 8/8 halo
+//   lanes, clamped at the edge = cv2's replicate border) and is the only thing written (+ columns
+//   0..6 of vsum for the row init).  D is stored in 64-row x 8-column tiles (4 KiB, one tile per
+//   channel), the unit k_hscan stages through LDS; inside a tile the 8 doubles of a row are
+//   XOR-swizzled by (row & 7) so that lanes reading "their" row spread over the LDS banks.  8
+//   consecutive lanes write one 64-byte half line.
 //
 // k_hscan (lanes along y, sequential in x): five horizontal running sums per row in one lane,
 //   2x2 solve per pixel.  Workgroup = 64 rows: wave 0 scans, wave 1 streams the next chunk's
 //   five tiles (20 KiB, perfectly coalesced) into the other LDS buffer; 40 KiB of LDS per
 //   workgroup keeps 4 workgroups on a CU, so a whole clip's rows are resident in one round.
 // ---------------------------------------------------------------------------------------
-constexpr int kStripW = 48;          // output columns per wave in k_vd: 64 lanes - 8 - 8 halo
+constexpr int kStripW = 48;          // output columns per wave in k_uv: 64 lanes - 8 - 8 halo
 
 __host__ __device__ constexpr int d16_xch(int w) { return (w + 7) / 8; }
 __host__ __device__ constexpr int d16_nyb(int h) { return (h + 63) / 64; }
 
 // ---------------------------------------------------------------------------------------
-// k_uv = k_update_matrices fused into k_vd: every lane evaluates the normal equations of its
+// k_uv = FarnebackUpdateMatrices fused into the vertical pass: every lane evaluates the normal equations of its
 // column row by row and feeds them straight into the vertical running sums, so the five M
 // planes never exist in memory.  A row's evaluation needs two dependent memory round trips
 // (flow/R0, then the bilinear gather of R1 at the warped position); they are software

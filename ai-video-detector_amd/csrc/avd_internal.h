@@ -91,7 +91,6 @@ struct Workspace {
     // farneback
     float* d_pyr[AVD_FB_LEVELS] = {};     // [n][hL*wL]
     float* d_poly[AVD_FB_LEVELS] = {};    // [n][hL*wL][5] interleaved polynomial coefficients
-    float* d_tmp = nullptr;               // row-filtered scratch [n][320*320]
     float* d_flow[AVD_FB_LEVELS] = {};    // [n-1][2][hL*wL]  planar
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
@@ -99,7 +98,6 @@ struct Workspace {
     float* d_stats = nullptr;             // [n-1][2] mean, var
     float* d_part = nullptr;              // [n-1][2][13] per-buffer partial sums (numpy reduction order)
     avd_frame_record* d_rec = nullptr;    // [n]
-    avd_frame_record* h_rec = nullptr;    // pinned [n]
 };
 
 struct avd_ctx {
