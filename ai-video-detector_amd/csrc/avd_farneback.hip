@@ -420,6 +420,27 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
     }
 }
 
+// staging registers of the loader wave: one chunk = 5 channels x 4 x 16 B per lane
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+struct ChunkRegs { dbl2 v[5][4]; };
+
+__device__ __forceinline__ void chunk_issue(ChunkRegs& r, const double* tiles, int xch, int xc, int lane)
+{
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            r.v[c][i] = *reinterpret_cast<const dbl2*>(tiles + ((int64_t)c * xch + xc) * 512 + i * 128 + lane * 2);
+}
+
+__device__ __forceinline__ void chunk_commit(const ChunkRegs& r, double (*buf)[512], int lane)
+{
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<dbl2*>(&buf[c][i * 128 + lane * 2]) = r.v[c][i];
+}
+
 template <int W>
 __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, const double* __restrict__ VS0,
                                               float* __restrict__ flow, int npairs)
@@ -432,26 +453,35 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     const int p = blockIdx.x / NYB, ybk = blockIdx.x - p * NYB;
     const double* tiles = D16 + ((int64_t)p * NYB + ybk) * 5 * XCH * 512;   // [c][xc][512]
 
-    // loader (wave 1): the tile image is copied verbatim, 16 B per lane, 4 KiB per channel
-    auto load_chunk = [&](int xc, int buf) {
-        double2 st[5][4];
-#pragma unroll
-        for (int c = 0; c < 5; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                st[c][i] = *reinterpret_cast<const double2*>(tiles + ((int64_t)c * XCH + xc) * 512 + i * 128 + lane * 2);
-#pragma unroll
-        for (int c = 0; c < 5; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) *reinterpret_cast<double2*>(&lds[buf][c][i * 128 + lane * 2]) = st[c][i];
-    };
+    if (wave == 1) {
+        // loader: the tile image is copied verbatim (16 B per lane, 4 KiB per channel).  Chunk xc+2 is in
+        // flight into one register set while chunk xc+1 (the other set) is written to the LDS buffer the
+        // scanner released last: two chunks (40 KiB) in flight per workgroup with two LDS buffers.
+        ChunkRegs ra, rb;
+        chunk_issue(ra, tiles, XCH, 0, lane);
+        if (XCH > 1) chunk_issue(rb, tiles, XCH, 1, lane);
+        chunk_commit(ra, lds[0], lane);
+        __syncthreads();
+        for (int xc = 0; xc < XCH; xc += 2) {
+            if (xc + 2 < XCH) chunk_issue(ra, tiles, XCH, xc + 2, lane);
+            if (xc + 1 < XCH) chunk_commit(rb, lds[1], lane);
+            __syncthreads();
+            if (xc + 1 < XCH) {
+                if (xc + 3 < XCH) chunk_issue(rb, tiles, XCH, xc + 3, lane);
+                if (xc + 2 < XCH) chunk_commit(ra, lds[0], lane);
+                __syncthreads();
+            }
+        }
+        return;
+    }
 
+    // scanner (wave 0)
     const int y = ybk * 64 + lane;
     const bool live = y < H;
     const int yc = min(y, H - 1);
-    double g[5] = {0, 0, 0, 0, 0};
+    double g[5];
     float* fl = flow + (int64_t)p * 2 * plane + yc * W;
-    if (wave == 0) {
+    {
         const double* v0 = VS0 + ((int64_t)p * 5 * H + yc) * 8;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -461,35 +491,28 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
             for (int k = 1; k < m; k++) s += vc[k];
             g[c] = s;
         }
-    } else {
-        load_chunk(0, 0);
     }
     __syncthreads();
     const double scale = 1. / (15 * 15);
     for (int xc = 0; xc < XCH; xc++) {
-        const int buf = xc & 1;
-        if (wave == 1) {
-            if (xc + 1 < XCH) load_chunk(xc + 1, buf ^ 1);
-        } else {
-            const int sw = lane & 7;
-            float ox[8], oy[8];
+        const int buf = xc & 1, sw = lane & 7;
+        float ox[8], oy[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < 8; j++) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) g[c] += lds[buf][c][lane * 8 + (j ^ sw)];
-                const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
-                const double h1 = g[3] * scale, h2 = g[4] * scale;
-                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                ox[j] = (float)((g11 * h2 - g12 * h1) * idet);
-                oy[j] = (float)((g22 * h1 - g12 * h2) * idet);
-            }
-            if (live) {
-                float* o = fl + xc * 8;
-                *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-                *reinterpret_cast<float4*>(o + 4) = make_float4(ox[4], ox[5], ox[6], ox[7]);
-                *reinterpret_cast<float4*>(o + plane) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-                *reinterpret_cast<float4*>(o + plane + 4) = make_float4(oy[4], oy[5], oy[6], oy[7]);
-            }
+            for (int c = 0; c < 5; c++) g[c] += lds[buf][c][lane * 8 + (j ^ sw)];
+            const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+            const double h1 = g[3] * scale, h2 = g[4] * scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            ox[j] = (float)((g11 * h2 - g12 * h1) * idet);
+            oy[j] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        if (live) {
+            float* o = fl + xc * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(ox[4], ox[5], ox[6], ox[7]);
+            *reinterpret_cast<float4*>(o + plane) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+            *reinterpret_cast<float4*>(o + plane + 4) = make_float4(oy[4], oy[5], oy[6], oy[7]);
         }
         __syncthreads();
     }
