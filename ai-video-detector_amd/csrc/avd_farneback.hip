@@ -16,6 +16,7 @@
 //     read 10 consecutive floats), flow planar, D tiled + XOR-swizzled.
 // Not GEMM-shaped (11/19-tap separable stencils, 15x15 box sums, per-pixel 2x2 solves): HBM-traffic
 // bound by the exact re-enactment of cv2's running double sums; MFMA is not applicable.
+#include <cstdlib>
 #include "avd_internal.h"
 
 #pragma clang fp contract(off)
@@ -310,6 +311,145 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
     M[2] = r5 * r5 + r6 * r6;
     M[3] = r4 * r2 + r6 * r3;
     M[4] = r6 * r2 + r5 * r3;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_uvp: the same computation as a producer / consumer workgroup.  Per row of a strip, ~80 % of the
+// instructions (loads, bilinear gather, normal equations, D difference, stores) do not depend on the
+// previous row; only five double adds per row chain.  With fewer strips than SIMDs a single wave per
+// strip is instruction-issue bound, so a strip gets FIVE waves:
+//   waves 1..4 (producers): wave w evaluates the normal equations of entry 4k+(w-1) in phase k
+//       (entry e = image row min(e, H-1); entries 0..6 initialise the box, entry y+7 enters at step y)
+//       and, two phases later, forms D = vsum(x+7)-vsum(x-8) of that step from LDS and stores it;
+//   wave 0 (consumer): walks the entries in order, keeps the last 16 rows in a register ring, runs the
+//       five running double sums and publishes vsum rows to LDS.
+// Hand-off through double-buffered LDS (M rows float, vsum rows double), ONE barrier per 4 rows.
+// Producers software-pipeline their own entries (stride 4 rows): flow/R0 loads three phases ahead,
+// gathers one phase ahead, static register slots.
+// ---------------------------------------------------------------------------------------
+constexpr int kUvpThreads = 320;
+
+template <int W>
+__global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
+                                                       double* __restrict__ D16, double* __restrict__ VS0, int npairs)
+{
+    constexpr int H = W, m = 7;
+    constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W), NYB = d16_nyb(H);
+    constexpr int plane = W * H;
+    constexpr int NE = H + m;                            // entries
+    constexpr int NP = (NE + 3) / 4;                     // producing phases
+    constexpr int NPH = ((NP + 2 + 3) / 4) * 4;          // loop trip count (drain + round up to the unroll)
+    __shared__ float Mb[2][4][5][64];
+    __shared__ double Vb[2][4][5][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x / NSTRIP, strip = blockIdx.x - p * NSTRIP;
+    const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
+    const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
+    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
+    const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
+    const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
+    const unsigned dbase = ((unsigned)p * NYB * 5 * XCH + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+    const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+    const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
+
+    if (wave == 0) {
+        // ------------------------------- consumer -------------------------------------------
+        float ring[16][5];
+        double vs[5] = {0, 0, 0, 0, 0};
+        for (int kb = 0; kb < NPH; kb += 4) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int k = kb + kk;                   // consumes the entries produced in phase k-1
+                if (k >= 1 && k - 1 < NP) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int kp = (kk + 3) & 3;         // (k-1) & 3, static
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int e = 4 * (k - 1) + i;
+                        const int es = (4 * kp + i) & 15;          // e & 15, static
+                        if (e < NE) {
+                            float a[5];
+#pragma unroll
+                            for (int c = 0; c < 5; c++) a[c] = Mb[kp & 1][i][c][lane];
+                            if (e < m) {
+#pragma unroll
+                                for (int c = 0; c < 5; c++) ring[es][c] = a[c];
+                                if (e == m - 1) {
+#pragma unroll
+                                    for (int c = 0; c < 5; c++) {
+                                        vs[c] = (double)(ring[0][c] * (float)(m + 2));
+#pragma unroll
+                                        for (int r = 1; r < m; r++) vs[c] += (double)ring[r][c];
+                                    }
+                                }
+                            } else {
+                                const int y = e - m;
+#pragma unroll
+                                for (int c = 0; c < 5; c++) {
+                                    const float b = y >= m + 1 ? ring[(es + 1) & 15][c] : ring[0][c];
+                                    ring[es][c] = a[c];
+                                    vs[c] += (double)(a[c] - b);
+                                    Vb[kp & 1][i][c][lane] = vs[c];
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ----------------------------------- producers ------------------------------------------
+    const int pi = wave - 1;                             // entry index inside a phase
+    NeIn in[4]; NeG g[2];
+    auto row_of = [&](int k) { return min(4 * k + pi, H - 1); };
+#pragma unroll
+    for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
+    ne_gather(R, r1base, in[0], x, row_of(0), W, H, plane, g[0]);
+    for (int kb = 0; kb < NPH; kb += 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = kb + kk;
+            if (k < NP) {
+                const int e = 4 * k + pi;
+                if (e < NE) {
+                    float a[5];
+                    ne_finish(in[kk], g[kk & 1], x, row_of(k), W, H, a);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) Mb[kk & 1][pi][c][lane] = a[c];
+                }
+                // refill: gathers of this wave's next entry, inputs three entries ahead
+                ne_gather(R, r1base, in[(kk + 1) & 3], x, row_of(k + 1), W, H, plane, g[(kk + 1) & 1]);
+                ne_load(R, flow, r0base, flbase, x, row_of(k + 3), W, plane, in[(kk + 3) & 3]);
+            }
+            if (k >= 2 && k - 2 < NP) {
+                // D and stores of the step whose vsum row the consumer published in phase k-1
+                const int e = 4 * (k - 2) + pi, y = e - m;
+                if (y >= 0 && y < H) {
+                    const int vb = kk & 1;               // (k-2) & 1
+                    double dv[5], hv[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        dv[c] = Vb[vb][pi][c][lhi] - Vb[vb][pi][c][llo];
+                        hv[c] = Vb[vb][pi][c][lane];
+                    }
+                    if (writer) {
+                        const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
+                        const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
+#pragma unroll
+                        for (int c = 0; c < 5; c++) D16[t0 + (unsigned)c * XCH * 512u] = dv[c];
+                    }
+                    if (head) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = hv[c];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 template <int W>
@@ -663,9 +803,17 @@ template <int W>
 void blur_iteration(const Seg& g, int k, int np)
 {
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    const int waves = np * NSTRIP;
-    hipLaunchKernelGGL(k_uv<W>, dim3((waves + 3) / 4), dim3(256), 0, g.stream, (const float*)g.poly[k],
-                       (const float*)g.flow[k], g.vs, g.vs0, np);
+    // AVD_UV_VARIANT: 0 = single-wave k_uv everywhere, 1 = producer/consumer k_uvp everywhere,
+    // 2 (default) = k_uvp below full resolution (issue-bound levels), k_uv at 320x320 (bandwidth-bound)
+    static const int variant = [] { const char* e = std::getenv("AVD_UV_VARIANT"); return e ? std::atoi(e) : 2; }();
+    if (variant == 1 || (variant == 2 && W < S)) {
+        hipLaunchKernelGGL(k_uvp<W>, dim3(np * NSTRIP), dim3(kUvpThreads), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
+    } else {
+        const int waves = np * NSTRIP;
+        hipLaunchKernelGGL(k_uv<W>, dim3((waves + 3) / 4), dim3(256), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
+    }
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,
                        (const double*)g.vs0, g.flow[k], np);
 }
