@@ -164,7 +164,7 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
     if (int e = dev_alloc(ctx, ws.d_vs0, np * 5 * AVD_SMALL * 8)) return e;
     if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
     if (int e = dev_alloc(ctx, ws.d_part, np * 2 * 16)) return e;
-    if (int e = dev_alloc(ctx, ws.d_vs, np * 5 * AVD_NPIX)) return e;
+    if (int e = dev_alloc(ctx, ws.d_vs, np * (5 * AVD_NPIX + 512))) return e;      // + one pad tile per pair
     (void)n;
     return 0;
 }

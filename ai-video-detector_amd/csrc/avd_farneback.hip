@@ -225,6 +225,9 @@ constexpr int kStripW = 48;          // output columns per wave in k_uv: 64 lane
 
 __host__ __device__ constexpr int d16_xch(int w) { return (w + 7) / 8; }
 __host__ __device__ constexpr int d16_nyb(int h) { return (h + 63) / 64; }
+// tiles per pair, padded to an ODD count: an unpadded 320x320 pair is exactly 4 MiB, and a power-of-two
+// stride between the pairs that all workgroups touch in lock step lands on the same HBM channels
+__host__ __device__ constexpr int d16_pair_tiles(int w) { return (d16_nyb(w) * 5 * d16_xch(w)) | 1; }
 
 // ---------------------------------------------------------------------------------------
 // k_uv = FarnebackUpdateMatrices fused into the vertical pass: every lane evaluates the normal equations of its
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict_
                                                        double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
     constexpr int H = W, m = 7;
-    constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W), NYB = d16_nyb(H);
+    constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
     constexpr int NE = H + m;                            // entries
     constexpr int NP = (NE + 3) / 4;                     // producing phases
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict_
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
     const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
     const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-    const unsigned dbase = ((unsigned)p * NYB * 5 * XCH + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+    const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
     const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
     const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
 
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
                                            double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
     constexpr int H = W, m = 7;
-    constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W), NYB = d16_nyb(H);
+    constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
     __shared__ double xch[4][2][5][64];
     const int wv = threadIdx.x >> 6;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;   // R[frame p], R[frame p+1]
     const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
     const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-    const unsigned dbase = ((unsigned)p * NYB * 5 * XCH + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+    const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
     const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
     double (*xw)[5][64] = xch[wv];
     const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     __shared__ __align__(16) double lds[2][5][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x / NYB, ybk = blockIdx.x - p * NYB;
-    const double* tiles = D16 + ((int64_t)p * NYB + ybk) * 5 * XCH * 512;   // [c][xc][512]
+    const double* tiles = D16 + ((int64_t)p * d16_pair_tiles(W) + (int64_t)ybk * 5 * XCH) * 512;   // [c][xc][512]
 
     if (wave == 1) {
         // loader: the tile image is copied verbatim (16 B per lane, 4 KiB per channel).  Chunk xc+2 is in
@@ -774,7 +777,7 @@ static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_of
         g.poly[k] = ws.d_poly[k] + (size_t)frame_off * 5 * plane;
         g.flow[k] = ws.d_flow[k] + (size_t)pair_off * 2 * plane;
     }
-    g.vs = ws.d_vs + (size_t)pair_off * 5 * AVD_NPIX;
+    g.vs = ws.d_vs + (size_t)pair_off * (5 * AVD_NPIX + 512);
     g.vs0 = ws.d_vs0 + (size_t)pair_off * 5 * S * 8;
     g.stats = ws.d_stats + (size_t)pair_off * 2;
     g.part = ws.d_part + (size_t)pair_off * 2 * 16;
