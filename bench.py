@@ -38,6 +38,22 @@ def algorithmic_bytes_per_frame(h, w):
     return h * w * 3 + 320 * 320 + 1024 + 16
 
 
+def farneback_model(n_frames, stage_ms):
+    """Second-largest view of the step: the Farneback stage (all pairs of the clip, 4 pyramid scales, 3
+    iterations).  'design_traffic' = bytes the two-kernel blur moves by construction per pixel and
+    iteration (D written + read back in double 80 B, R0 + R1 40 B, flow in + out 16 B); flop count from the
+    operation list in DESIGN.md 4.3 (~73 Mflop per pair).  It is bandwidth/latency bound, far from the
+    vector-FP32 roofline."""
+    pairs, px = max(n_frames - 1, 0), 320 * 320 + 160 * 160 + 80 * 80 + 40 * 40
+    traffic = pairs * px * 3 * 136
+    flops = pairs * 73e6
+    t = stage_ms * 1e-3
+    return {"stage": "Farneback + flow statistics", "avg_ms": round(stage_ms, 4), "bound": "hbm",
+            "design_traffic_bytes": traffic, "achieved": round(traffic / t / 1e9, 1) if t > 0 else 0.0,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
+            "flops": flops, "tflops": round(flops / t / 1e12, 2) if t > 0 else 0.0, "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF}
+
+
 def cpu_baseline(clip, meta, max_frames):
     """The CPU oracle (a port of the reference's cv2/numpy arithmetic, single thread like
     cv2's Farneback) timed on a bounded sample of the same clip."""
@@ -155,6 +171,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(pre_ms, 4),
                          "share_of_step": round(pre_ms / ms_per_step, 4)},
+            "roofline_farneback": farneback_model(n, float(stage[2])),
             "stages_ms": {"preprocess": round(float(stage[0]), 4), "hash_hamming_records": round(float(stage[1]), 4),
                           "farneback_and_flow_stats": round(float(stage[2]), 4), "records_copy_out": round(float(stage[3]), 4)},
             "result_check": {"ai_timeline_head": [round(v, 6) for v in result["timeline"][:3]],
