@@ -93,6 +93,16 @@ def main():
     import avd_hip
     from avd_hip import synth, dist as avd_dist
     from avd_hip.timeline import records_to_result
+    from avd_hip.pipeline import audio_unavailable
+    from app.analyzers import fusion, heuristics_v2
+    if local_rank == 0:
+        avd_hip.build()                             # no-op when the in-tree .so is up to date
+    else:                                           # other ranks wait for rank 0's build instead of racing it
+        from avd_hip import _lib as _avd_lib
+        for _ in range(600):
+            if os.path.exists(_avd_lib.SO_PATH):
+                break
+            time.sleep(0.2)
     avd_hip.load()                                  # fail loudly before anything else if the .so is missing
     import torch
     dev_index = int(os.environ.get("AVD_BENCH_DEVICE", local_rank))      # rehearsal: several ranks on one GPU
@@ -115,13 +125,16 @@ def main():
     ctx = avd_hip.Context(dev_index)
     ctx.set_profiling(True)
     rec = np.zeros(n, avd_hip.RECORD_DTYPE)
+    hints = heuristics_v2.compute_hints({**meta, "bit_rate": 8_000_000}, "")
 
     def step():
         ctx.analyze_frames_async(frames, rec)
         ctx.synchronize()
         allrec = avd_dist.gather_fixed(rec, device=gather_dev) if use_dist else rec
-        # scalar tail (video.py:54-83) for this rank's clip; other clips' records are now local too
-        return records_to_result(allrec[rank * n:(rank + 1) * n], h * w, w, h, meta["fps"], meta["duration"])
+        # scalar tail (video.py:54-83) + fusion (fusion.py:16) for this rank's clip; other clips' records are local too
+        video = records_to_result(allrec[rank * n:(rank + 1) * n], h * w, w, h, meta["fps"], meta["duration"])
+        fused = fusion.fuse(audio_unavailable("", meta), video, hints)
+        return video, fused
 
     def barrier():
         if use_dist:
@@ -134,7 +147,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = step()
+        result, fused = step()
         stage += np.array(ctx.stage_ms())
     barrier()
     elapsed = time.perf_counter() - t0
@@ -175,7 +188,7 @@ def main():
             "stages_ms": {"preprocess": round(float(stage[0]), 4), "hash_hamming_records": round(float(stage[1]), 4),
                           "farneback_and_flow_stats": round(float(stage[2]), 4), "records_copy_out": round(float(stage[3]), 4)},
             "result_check": {"ai_timeline_head": [round(v, 6) for v in result["timeline"][:3]],
-                             "dup_density": result["summary"]["dup_density"]},
+                             "dup_density": result["summary"]["dup_density"], **fused["result"]},
         }
         if args.pcie and world == 1:
             # boundary handing over HOST buffers: pinned host frames staged by hipMemcpyAsync inside the call

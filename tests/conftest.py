@@ -26,6 +26,7 @@ def oracle():
 def ctx():
     """One HIP context for the whole GPU session (fails loudly if the extension is missing)."""
     import avd_hip
+    avd_hip.build()                 # no-op when the in-tree .so is up to date (hipcc is on the GPU box too)
     c = avd_hip.Context(0)
     yield c
     c.close()

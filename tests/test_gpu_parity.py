@@ -189,3 +189,16 @@ def test_error_paths(ctx):
         ctx.preprocess_bgr(np.zeros((1, 16, 16, 3), np.uint8))     # < 32x32: unsupported
     rec = ctx.analyze_frames(np.zeros((1, 64, 64, 3), np.uint8))    # single frame: no flow
     assert rec["ham"][0] == -1 and rec["flow_mean"][0] == 0 and rec["lap_sumsq"][0] == 0
+
+
+def test_device_resident_inputs(ctx, oracle):
+    """Inputs already in HBM (torch-ROCm tensors): a strided frame view and the 320x320 stack."""
+    torch = pytest.importorskip("torch")
+    clip = synth.make_clip(5, 200, 336, seed=41)
+    big = torch.zeros((5, 208, 352, 3), dtype=torch.uint8, device="cuda:0")
+    big[:, :200, :336] = torch.from_numpy(clip).to("cuda:0")
+    rec = ctx.analyze_frames(big[:, :200, :336])                       # row stride 1056 B, frame stride with a gap
+    assert np.array_equal(rec, ctx.analyze_frames(clip))
+    small = np.stack([oracle.resize_linear(oracle.bgr2gray(f), 320, 320) for f in clip])
+    fm, fv = ctx.farneback_pairs(torch.from_numpy(small).to("cuda:0"))
+    assert np.array_equal(fm, rec["flow_mean"][1:]) and np.array_equal(fv, rec["flow_var"][1:])
