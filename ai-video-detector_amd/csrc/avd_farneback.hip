@@ -637,9 +637,8 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     }
     __syncthreads();
     const double scale = 1. / (15 * 15);
-    for (int xc = 0; xc < XCH; xc++) {
-        const int buf = xc & 1, sw = lane & 7;
-        float ox[8], oy[8];
+    const int sw = lane & 7;
+    auto scan8 = [&](int buf, float (&ox)[8], float (&oy)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
 #pragma unroll
@@ -650,14 +649,27 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
             ox[j] = (float)((g11 * h2 - g12 * h1) * idet);
             oy[j] = (float)((g22 * h1 - g12 * h2) * idet);
         }
+    };
+    auto store8 = [&](float* o, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    };
+    // two chunks per store: a lane writes 64 contiguous bytes per flow component (32-byte stores were
+    // counted as 1.65x their size in WRITE_SIZE: partial-line writes)
+    for (int xc = 0; xc < XCH; xc += 2) {
+        float ax[8], ay[8], bx[8], by[8];
+        scan8(0, ax, ay);
+        __syncthreads();
+        const bool second = xc + 1 < XCH;
+        if (second) scan8(1, bx, by);
         if (live) {
             float* o = fl + xc * 8;
-            *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(ox[4], ox[5], ox[6], ox[7]);
-            *reinterpret_cast<float4*>(o + plane) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-            *reinterpret_cast<float4*>(o + plane + 4) = make_float4(oy[4], oy[5], oy[6], oy[7]);
+            store8(o, ax);
+            if (second) store8(o + 8, bx);
+            store8(o + plane, ay);
+            if (second) store8(o + plane + 8, by);
         }
-        __syncthreads();
+        if (second) __syncthreads();
     }
 }
 
