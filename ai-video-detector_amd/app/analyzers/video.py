@@ -19,6 +19,7 @@ from avd_hip.timeline import records_to_result, sample_step
 
 _DEVICE = int(os.getenv("AVD_DEVICE", "0"))
 _CHUNK = int(os.getenv("AVD_CHUNK_FRAMES", "64"))      # sampled frames per HIP call (host memory bound)
+_SAMPLES_PER_SECOND = float(os.getenv("AVD_SAMPLES_PER_SECOND", "2"))   # extension knob; 2 = the reference (video.py:19)
 
 
 def analyze(path: str, meta: dict):
@@ -30,7 +31,7 @@ def analyze(path: str, meta: dict):
         w = meta.get("width") or int(src.width or 0)
         h = meta.get("height") or int(src.height or 0)
         duration = meta.get("duration") or (src.frame_count / fps if fps > 0 else 0.0)
-        step = sample_step(fps)
+        step = sample_step(fps, _SAMPLES_PER_SECOND)
 
         seen = {}
 

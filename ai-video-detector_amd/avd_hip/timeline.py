@@ -10,10 +10,12 @@ from __future__ import annotations
 import numpy as np
 
 
-def sample_step(fps) -> int:
+def sample_step(fps, per_second: float = 2) -> int:
     """Frame sampling stride, ~2 analysed frames per second (video.py:19).
-    Python's round() is half-to-even: 25 fps -> 12, 29.97 -> 15, 60 -> 30."""
-    return max(1, int(round((fps or 30) / 2)))
+    Python's round() is half-to-even: 25 fps -> 12, 29.97 -> 15, 60 -> 30.
+    ``per_second`` is a build extension (the reference hard-codes 2): BASELINE.json configs[3] asks for
+    dense 8 fps sampling, i.e. step = round(fps / 8); the default reproduces the reference."""
+    return max(1, int(round((fps or 30) / per_second)))
 
 
 def timeline_length(duration) -> int:

@@ -92,6 +92,7 @@ def test_host_tail_edge_cases():
     assert r["timeline"] == [1.0, 1.0, 1.0] and r["summary"]["flow_mean"] == 0.0
     assert [timeline.sample_step(f) for f in (25, 29.97, 23.976, 60, 0, None, 1)] == [12, 15, 12, 30, 15, 15, 1]
     assert [timeline.timeline_length(d) for d in (0, 0.4, 0.5, 1.5, 2.5, 59.6)] == [1, 1, 1, 2, 2, 60]
+    assert timeline.sample_step(30, 8) == 4 and timeline.sample_step(30, 2) == 15      # dense-sampling extension (cfg4)
 
 
 def test_unopenable_file_is_not_an_error(tmp_path):
