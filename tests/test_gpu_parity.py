@@ -202,3 +202,28 @@ def test_device_resident_inputs(ctx, oracle):
     small = np.stack([oracle.resize_linear(oracle.bgr2gray(f), 320, 320) for f in clip])
     fm, fv = ctx.farneback_pairs(torch.from_numpy(small).to("cuda:0"))
     assert np.array_equal(fm, rec["flow_mean"][1:]) and np.array_equal(fv, rec["flow_var"][1:])
+
+
+def test_two_threads_two_contexts(ctx):
+    """reference api.py:133 runs the analyzer on worker threads: one avd_ctx per thread, concurrently."""
+    import threading
+    import avd_hip
+    from avd_hip import analyzer
+    clips = [synth.make_clip(6, 120, 200, seed=s) for s in (51, 52)]
+    want = [ctx.analyze_frames(c) for c in clips]
+    got = [None, None]
+    ctxs = [None, None]
+
+    def work(i):
+        ctxs[i] = analyzer.thread_context(0)                  # thread-local context
+        for _ in range(3):
+            got[i] = ctxs[i].analyze_frames(clips[i])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert ctxs[0] is not ctxs[1] and ctxs[0] is not ctx
+    for i in range(2):
+        assert np.array_equal(got[i], want[i])
