@@ -330,20 +330,21 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
 // Producers software-pipeline their own entries (stride 4 rows): flow/R0 loads three phases ahead,
 // gathers one phase ahead, static register slots.
 // ---------------------------------------------------------------------------------------
-constexpr int kUvpThreads = 320;
-
-template <int W>
-__global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
-                                                       double* __restrict__ D16, double* __restrict__ VS0, int npairs)
+template <int W, int NPROD>
+__global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
+                                                           double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
+    static_assert(NPROD == 3 || NPROD == 4, "ring / unroll constants below cover 3 or 4 producers");
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
+    constexpr int RS = NPROD == 4 ? 16 : 18;             // register ring of the consumer: >= 16 rows, multiple of NPROD
+    constexpr int U = NPROD == 4 ? 4 : 12;               // phases per unrolled body: multiple of RS/NPROD and of 4 (producer slots)
     constexpr int NE = H + m;                            // entries
-    constexpr int NP = (NE + 3) / 4;                     // producing phases
-    constexpr int NPH = ((NP + 2 + 3) / 4) * 4;          // loop trip count (drain + round up to the unroll)
-    __shared__ float Mb[2][4][5][64];
-    __shared__ double Vb[2][4][5][64];
+    constexpr int NP = (NE + NPROD - 1) / NPROD;         // producing phases
+    constexpr int NPH = ((NP + 2 + U - 1) / U) * U;      // loop trip count (drain + round up to the unroll)
+    __shared__ float Mb[2][NPROD][5][64];
+    __shared__ double Vb[2][NPROD][5][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x / NSTRIP, strip = blockIdx.x - p * NSTRIP;
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
@@ -357,19 +358,18 @@ __global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict_
 
     if (wave == 0) {
         // ------------------------------- consumer -------------------------------------------
-        float ring[16][5];
+        float ring[RS][5];
         double vs[5] = {0, 0, 0, 0, 0};
-        for (int kb = 0; kb < NPH; kb += 4) {
+        for (int kb = 0; kb < NPH; kb += U) {
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
+            for (int kk = 0; kk < U; kk++) {
                 const int k = kb + kk;                   // consumes the entries produced in phase k-1
                 if (k >= 1 && k - 1 < NP) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int kp = (kk + 3) & 3;         // (k-1) & 3, static
+                    const int kp = (kk + U - 1) % U;     // (k-1) mod U, static
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int e = 4 * (k - 1) + i;
-                        const int es = (4 * kp + i) & 15;          // e & 15, static
+                    for (int i = 0; i < NPROD; i++) {
+                        const int e = NPROD * (k - 1) + i;
+                        const int es = (NPROD * kp + i) % RS;      // e mod RS, static (NPROD*U is a multiple of RS)
                         if (e < NE) {
                             float a[5];
 #pragma unroll
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict_
                                 const int y = e - m;
 #pragma unroll
                                 for (int c = 0; c < 5; c++) {
-                                    const float b = y >= m + 1 ? ring[(es + 1) & 15][c] : ring[0][c];
+                                    const float b = y >= m + 1 ? ring[(es + RS - 15) % RS][c] : ring[0][c];   // row y-8 = e-15
                                     ring[es][c] = a[c];
                                     vs[c] += (double)(a[c] - b);
                                     Vb[kp & 1][i][c][lane] = vs[c];
@@ -407,19 +407,19 @@ __global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict_
     // ----------------------------------- producers ------------------------------------------
     const int pi = wave - 1;                             // entry index inside a phase
     NeIn in[4]; NeG g[2];
-    auto row_of = [&](int k) { return min(4 * k + pi, H - 1); };
+    auto row_of = [&](int k) { return min(NPROD * k + pi, H - 1); };
 #pragma unroll
     for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
     ne_gather(R, r1base, in[0], x, row_of(0), W, H, plane, g[0]);
-    for (int kb = 0; kb < NPH; kb += 4) {
+    for (int kb = 0; kb < NPH; kb += U) {
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
+        for (int kk = 0; kk < U; kk++) {
             const int k = kb + kk;
             if (k < NP) {
-                const int e = 4 * k + pi;
+                const int e = NPROD * k + pi;
                 if (e < NE) {
                     float a[5];
-                    ne_finish(in[kk], g[kk & 1], x, row_of(k), W, H, a);
+                    ne_finish(in[kk & 3], g[kk & 1], x, row_of(k), W, H, a);
 #pragma unroll
                     for (int c = 0; c < 5; c++) Mb[kk & 1][pi][c][lane] = a[c];
                 }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kUvpThreads, 4) void k_uvp(const float* __restrict_
             }
             if (k >= 2 && k - 2 < NP) {
                 // D and stores of the step whose vsum row the consumer published in phase k-1
-                const int e = 4 * (k - 2) + pi, y = e - m;
+                const int e = NPROD * (k - 2) + pi, y = e - m;
                 if (y >= 0 && y < H) {
                     const int vb = kk & 1;               // (k-2) & 1
                     double dv[5], hv[5];
@@ -818,11 +818,15 @@ template <int W>
 void blur_iteration(const Seg& g, int k, int np)
 {
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    // AVD_UV_VARIANT: 0 = single-wave k_uv everywhere, 1 = producer/consumer k_uvp everywhere,
-    // 2 (default) = k_uvp below full resolution (issue-bound levels), k_uv at 320x320 (bandwidth-bound)
+    // AVD_UV_VARIANT: 0 = single-wave k_uv everywhere, 1 = producer/consumer k_uvp<4 producers> everywhere,
+    // 2 (default) = k_uvp<4> below full resolution (issue-bound levels), k_uv at 320x320 (bandwidth-bound),
+    // 3 = k_uvp<3 producers> everywhere, 4 = k_uvp<3> at 320x320 + k_uvp<4> below
     static const int variant = [] { const char* e = std::getenv("AVD_UV_VARIANT"); return e ? std::atoi(e) : 2; }();
-    if (variant == 1 || (variant == 2 && W < S)) {
-        hipLaunchKernelGGL(k_uvp<W>, dim3(np * NSTRIP), dim3(kUvpThreads), 0, g.stream, (const float*)g.poly[k],
+    if (variant == 3 || (variant == 4 && W == S)) {
+        hipLaunchKernelGGL((k_uvp<W, 3>), dim3(np * NSTRIP), dim3(256), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
+    } else if (variant == 1 || ((variant == 2 || variant == 4) && W < S)) {
+        hipLaunchKernelGGL((k_uvp<W, 4>), dim3(np * NSTRIP), dim3(320), 0, g.stream, (const float*)g.poly[k],
                            (const float*)g.flow[k], g.vs, g.vs0, np);
     } else {
         const int waves = np * NSTRIP;
