@@ -592,6 +592,7 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     constexpr int XCH = d16_xch(W), NYB = d16_nyb(H);
     constexpr int64_t plane = (int64_t)W * H;
     __shared__ __align__(16) double lds[2][5][512];
+    __shared__ __align__(16) float outb[2][64][20];      // row stride 80 B: ds_write_b128 of 8 lanes covers all banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x / NYB, ybk = blockIdx.x - p * NYB;
     const double* tiles = D16 + ((int64_t)p * d16_pair_tiles(W) + (int64_t)ybk * 5 * XCH) * 512;   // [c][xc][512]
@@ -605,7 +606,20 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
         if (XCH > 1) chunk_issue(rb, tiles, XCH, 1, lane);
         chunk_commit(ra, lds[0], lane);
         __syncthreads();
-        for (int xc = 0; xc < XCH; xc += 2) {
+        int xc = 0;
+        // steady state without conditionals: behind an `if` the compiler has to assume the loads were skipped
+        // and waits vmcnt(19..0) for the commit, i.e. for the chunk it has just issued as well
+        for (; xc + 3 < XCH; xc += 2) {
+            chunk_issue(ra, tiles, XCH, xc + 2, lane);
+            __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the LDS writes of the other set
+            chunk_commit(rb, lds[1], lane);
+            __syncthreads();
+            chunk_issue(rb, tiles, XCH, xc + 3, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk_commit(ra, lds[0], lane);
+            __syncthreads();
+        }
+        for (; xc < XCH; xc += 2) {
             if (xc + 2 < XCH) chunk_issue(ra, tiles, XCH, xc + 2, lane);
             if (xc + 1 < XCH) chunk_commit(rb, lds[1], lane);
             __syncthreads();
@@ -620,10 +634,8 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
 
     // scanner (wave 0)
     const int y = ybk * 64 + lane;
-    const bool live = y < H;
     const int yc = min(y, H - 1);
     double g[5];
-    float* fl = flow + (int64_t)p * 2 * plane + yc * W;
     {
         const double* v0 = VS0 + ((int64_t)p * 5 * H + yc) * 8;
 #pragma unroll
@@ -650,25 +662,43 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
             oy[j] = (float)((g22 * h1 - g12 * h2) * idet);
         }
     };
-    auto store8 = [&](float* o, const float (&v)[8]) {
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    };
-    // two chunks per store: a lane writes 64 contiguous bytes per flow component (32-byte stores were
-    // counted as 1.65x their size in WRITE_SIZE: partial-line writes)
+    // Results leave through a small LDS transpose: a lane owns a ROW, so direct stores would touch 64
+    // different lines with 16 B each per instruction (measured: 43 of the kernel's 153 us at 320 px).
+    // Re-read as [16 rows][4 lanes x 16 B], one store instruction covers 16 rows x 64 contiguous bytes.
+    const int tr = lane >> 2, tq = lane & 3;
+    float* fout = flow + (int64_t)p * 2 * plane + (int64_t)(ybk * 64 + tr) * W + tq * 4;
     for (int xc = 0; xc < XCH; xc += 2) {
         float ax[8], ay[8], bx[8], by[8];
         scan8(0, ax, ay);
         __syncthreads();
         const bool second = xc + 1 < XCH;
         if (second) scan8(1, bx, by);
-        if (live) {
-            float* o = fl + xc * 8;
-            store8(o, ax);
-            if (second) store8(o + 8, bx);
-            store8(o + plane, ay);
-            if (second) store8(o + plane + 8, by);
+        {
+            float4* ox = reinterpret_cast<float4*>(outb[0][lane]);
+            float4* oy = reinterpret_cast<float4*>(outb[1][lane]);
+            ox[0] = make_float4(ax[0], ax[1], ax[2], ax[3]); ox[1] = make_float4(ax[4], ax[5], ax[6], ax[7]);
+            oy[0] = make_float4(ay[0], ay[1], ay[2], ay[3]); oy[1] = make_float4(ay[4], ay[5], ay[6], ay[7]);
+            if (second) {
+                ox[2] = make_float4(bx[0], bx[1], bx[2], bx[3]); ox[3] = make_float4(bx[4], bx[5], bx[6], bx[7]);
+                oy[2] = make_float4(by[0], by[1], by[2], by[3]); oy[3] = make_float4(by[4], by[5], by[6], by[7]);
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (second || tq < 2) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = tr + 16 * k;
+                if (ybk * 64 + r < H) {
+                    float* o = fout + (int64_t)k * 16 * W + xc * 8;
+                    *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(&outb[0][r][tq * 4]);
+                    *reinterpret_cast<float4*>(o + plane) = *reinterpret_cast<const float4*>(&outb[1][r][tq * 4]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (second) __syncthreads();
     }
 }
