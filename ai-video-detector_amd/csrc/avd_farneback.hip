@@ -207,19 +207,23 @@ __global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev,
 // rounds at every slide, so the value at (y,x) depends on the whole column / row prefix; the
 // chains are reproduced literally, one lane per chain, in two kernels:
 //
-// k_uv  (lanes along x, sequential in y; defined further down): FarnebackUpdateMatrices fused with the
-//   vertical running sums vsum in double.  The horizontal pass only ever needs
-//   D(x) = vsum(x+7) - vsum(x-8), which is formed there (a wave owns 48 output columns + 8/8 halo
+// k_uv / k_uvp (lanes along x, sequential in y; defined further down): FarnebackUpdateMatrices fused with
+//   the vertical running sums vsum in double.  The horizontal pass only ever needs
+//   D(x) = vsum(x+7) - vsum(x-8), which is formed there (a strip owns 48 output columns + 8/8 halo
 //   lanes, clamped at the edge = cv2's replicate border) and is the only thing written (+ columns
 //   0..6 of vsum for the row init).  D is stored in 64-row x 8-column tiles (4 KiB, one tile per
 //   channel), the unit k_hscan stages through LDS; inside a tile the 8 doubles of a row are
 //   XOR-swizzled by (row & 7) so that lanes reading "their" row spread over the LDS banks.  8
-//   consecutive lanes write one 64-byte half line.
+//   consecutive lanes write one 64-byte half line.  In both kernels the waves that LOAD never STORE
+//   (one in-order vmcnt for both on this hardware) and their steps have no branches around memory
+//   operations (a conditional load or store makes every later s_waitcnt conservative).
 //
 // k_hscan (lanes along y, sequential in x): five horizontal running sums per row in one lane,
-//   2x2 solve per pixel.  Workgroup = 64 rows: wave 0 scans, wave 1 streams the next chunk's
-//   five tiles (20 KiB, perfectly coalesced) into the other LDS buffer; 40 KiB of LDS per
-//   workgroup keeps 4 workgroups on a CU, so a whole clip's rows are resident in one round.
+//   2x2 solve per pixel.  Workgroup = 64 rows: wave 0 scans, wave 1 streams the next chunks'
+//   five tiles (20 KiB each, perfectly coalesced, two chunks in flight in registers) into the other
+//   LDS buffer; the flow leaves through a 10 KiB LDS transpose so that a store instruction writes 64
+//   contiguous bytes per row instead of 16.  50 KiB of LDS per workgroup = 3 workgroups per CU, so a
+//   whole clip's row blocks (595 at 320 px) are resident in one round.
 // ---------------------------------------------------------------------------------------
 constexpr int kStripW = 48;          // output columns per wave in k_uv: 64 lanes - 8 - 8 halo
 
@@ -235,9 +239,9 @@ __host__ __device__ constexpr int d16_pair_tiles(int w) { return (d16_nyb(w) * 5
 // planes never exist in memory.  A row's evaluation needs two dependent memory round trips
 // (flow/R0, then the bilinear gather of R1 at the warped position); they are software
 // pipelined by hand: at the step that consumes row r, the gathers of row r+2 and the flow/R0
-// loads of row r+4 are issued (explicit register stages -- the compiler does not hoist loads
-// across the predicated stores).  vsum(x+7)/vsum(x-8) are exchanged through a wave-private LDS
-// row (ds_bpermute costs ~20 cycles per wave64 on gfx950, an LDS write + two reads ~1/3 of that).
+// loads of row r+4 are issued (explicit register stages).  The vsum rows go to LDS, where the strip's
+// second wave forms vsum(x+7) - vsum(x-8) and stores it (ds_bpermute would cost ~20 cycles per wave64 on
+// gfx950, an LDS write + two reads ~1/3 of that).
 // ---------------------------------------------------------------------------------------
 struct NeIn { float dx, dy, r0[5]; };
 struct NeG { float top[10], bot[10]; };            // (y1,x1..x1+1) and (y1+1,x1..x1+1), 5 coefficients each
@@ -278,35 +282,34 @@ __device__ __forceinline__ void ne_gather(const float* __restrict__ R, unsigned 
 
 __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, int y, int w, int h, float (&M)[5])
 {
+    // Branch-free on purpose (selects, multiplication by an exact 1.0f): a conditional block here lets the
+    // compiler sink the gathered loads into it, right in front of their use, and makes its vmcnt counts
+    // conservative at the join -- either way the software pipeline of k_uv / k_uvp collapses.
     const float dx = in.dx, dy = in.dy;
     float fx = x + dx, fy = y + dy;
     const int x1 = floor_f(fx), y1 = floor_f(fy);
-    float r2, r3, r4, r5, r6;
     fx -= x1; fy -= y1;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        r2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
-        r3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
-        r4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
-        r5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
-        r6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
-        r4 = (in.r0[2] + r4) * 0.5f;
-        r5 = (in.r0[3] + r5) * 0.5f;
-        r6 = (in.r0[4] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = in.r0[2];
-        r5 = in.r0[3];
-        r6 = in.r0[4] * 0.5f;
-    }
+    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const float b2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
+    const float b3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
+    const float b4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
+    const float b5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
+    const float b6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
+    float r2 = inside ? b2 : 0.f, r3 = inside ? b3 : 0.f;
+    float r4 = inside ? (in.r0[2] + b4) * 0.5f : in.r0[2];
+    float r5 = inside ? (in.r0[3] + b5) * 0.5f : in.r0[3];
+    float r6 = inside ? (in.r0[4] + b6) * 0.25f : in.r0[4] * 0.5f;
     r2 = (in.r0[0] - r2) * 0.5f;
     r3 = (in.r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
-    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
+    {
         auto border = [](int d) { return d < 2 ? 0.14f : 0.4472f; };      // {.14,.14,.4472,.4472,.4472}
-        const float scale = (x < 5 ? border(x) : 1.f) * (x >= w - 5 ? border(w - x - 1) : 1.f) *
-                            (y < 5 ? border(y) : 1.f) * (y >= h - 5 ? border(h - y - 1) : 1.f);
+        const bool edge = (unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10);
+        const float sc = (x < 5 ? border(x) : 1.f) * (x >= w - 5 ? border(w - x - 1) : 1.f) *
+                         (y < 5 ? border(y) : 1.f) * (y >= h - 5 ? border(h - y - 1) : 1.f);
+        const float scale = edge ? sc : 1.f;             // interior: x * 1.0f == x exactly
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
     M[0] = r4 * r4 + r6 * r6;
@@ -318,17 +321,18 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
 
 // ---------------------------------------------------------------------------------------
 // k_uvp: the same computation as a producer / consumer workgroup.  Per row of a strip, ~80 % of the
-// instructions (loads, bilinear gather, normal equations, D difference, stores) do not depend on the
-// previous row; only five double adds per row chain.  With fewer strips than SIMDs a single wave per
-// strip is instruction-issue bound, so a strip gets FIVE waves:
-//   waves 1..4 (producers): wave w evaluates the normal equations of entry 4k+(w-1) in phase k
-//       (entry e = image row min(e, H-1); entries 0..6 initialise the box, entry y+7 enters at step y)
-//       and, two phases later, forms D = vsum(x+7)-vsum(x-8) of that step from LDS and stores it;
+// instructions (loads, bilinear gather, normal equations) do not depend on the previous row; only five
+// double adds per row chain.  A strip gets NPROD + 1 waves:
+//   waves 1..NPROD (producers): wave w evaluates the normal equations of entry NPROD*k+(w-1) in phase k
+//       (entry e = image row min(e, H-1); entries 0..6 initialise the box, entry y+7 enters at step y).
+//       They only LOAD: loads and stores share one in-order vmcnt on this hardware, so a wave that also
+//       stores waits for its own store acknowledgements whenever it waits for a prefetched load;
 //   wave 0 (consumer): walks the entries in order, keeps the last 16 rows in a register ring, runs the
-//       five running double sums and publishes vsum rows to LDS.
-// Hand-off through double-buffered LDS (M rows float, vsum rows double), ONE barrier per 4 rows.
-// Producers software-pipeline their own entries (stride 4 rows): flow/R0 loads three phases ahead,
-// gathers one phase ahead, static register slots.
+//       five running double sums, exchanges vsum(x+7)/vsum(x-8) through a wave-private LDS row, and is
+//       the only wave that STORES (D tiles, vsum columns 0..6) -- it never waits on memory.
+// Hand-off through double-buffered LDS (M rows, float), ONE barrier per NPROD rows.  Producers
+// software-pipeline their own entries (stride NPROD rows): flow/R0 loads three phases ahead, gathers
+// one phase ahead, static register slots; their steps have no branches around memory operations.
 // ---------------------------------------------------------------------------------------
 template <int W, int NPROD>
 __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
@@ -342,22 +346,21 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
     constexpr int U = NPROD == 4 ? 4 : 12;               // phases per unrolled body: multiple of RS/NPROD and of 4 (producer slots)
     constexpr int NE = H + m;                            // entries
     constexpr int NP = (NE + NPROD - 1) / NPROD;         // producing phases
-    constexpr int NPH = ((NP + 2 + U - 1) / U) * U;      // loop trip count (drain + round up to the unroll)
+    constexpr int NPH = ((NP + 1 + U - 1) / U) * U;      // loop trip count (drain + round up to the unroll)
     __shared__ float Mb[2][NPROD][5][64];
-    __shared__ double Vb[2][NPROD][5][64];
+    __shared__ double Vb[5][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x / NSTRIP, strip = blockIdx.x - p * NSTRIP;
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
-    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
-    const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
-    const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-    const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
-    const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
-    const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
 
     if (wave == 0) {
         // ------------------------------- consumer -------------------------------------------
+        const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
+        const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
+        const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+        const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+        const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
         float ring[RS][5];
         double vs[5] = {0, 0, 0, 0, 0};
         for (int kb = 0; kb < NPH; kb += U) {
@@ -392,7 +395,22 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
                                     const float b = y >= m + 1 ? ring[(es + RS - 15) % RS][c] : ring[0][c];   // row y-8 = e-15
                                     ring[es][c] = a[c];
                                     vs[c] += (double)(a[c] - b);
-                                    Vb[kp & 1][i][c][lane] = vs[c];
+                                    Vb[c][lane] = vs[c];
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                                double dv[5];
+#pragma unroll
+                                for (int c = 0; c < 5; c++) dv[c] = Vb[c][lhi] - Vb[c][llo];
+                                __builtin_amdgcn_wave_barrier();
+                                if (writer) {
+                                    const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
+                                    const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
+#pragma unroll
+                                    for (int c = 0; c < 5; c++) D16[t0 + (unsigned)c * XCH * 512u] = dv[c];
+                                }
+                                if (head) {
+#pragma unroll
+                                    for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = vs[c];
                                 }
                             }
                         }
@@ -405,6 +423,7 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
     }
 
     // ----------------------------------- producers ------------------------------------------
+    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
     const int pi = wave - 1;                             // entry index inside a phase
     NeIn in[4]; NeG g[2];
     auto row_of = [&](int k) { return min(NPROD * k + pi, H - 1); };
@@ -416,39 +435,15 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
         for (int kk = 0; kk < U; kk++) {
             const int k = kb + kk;
             if (k < NP) {
-                const int e = NPROD * k + pi;
-                if (e < NE) {
-                    float a[5];
-                    ne_finish(in[kk & 3], g[kk & 1], x, row_of(k), W, H, a);
+                // rows past the last entry (e >= NE, only in the final phase) are evaluated on clamped
+                // addresses and never consumed: no branch around the loads
+                float a[5];
+                ne_finish(in[kk & 3], g[kk & 1], x, row_of(k), W, H, a);
 #pragma unroll
-                    for (int c = 0; c < 5; c++) Mb[kk & 1][pi][c][lane] = a[c];
-                }
+                for (int c = 0; c < 5; c++) Mb[kk & 1][pi][c][lane] = a[c];
                 // refill: gathers of this wave's next entry, inputs three entries ahead
                 ne_gather(R, r1base, in[(kk + 1) & 3], x, row_of(k + 1), W, H, plane, g[(kk + 1) & 1]);
                 ne_load(R, flow, r0base, flbase, x, row_of(k + 3), W, plane, in[(kk + 3) & 3]);
-            }
-            if (k >= 2 && k - 2 < NP) {
-                // D and stores of the step whose vsum row the consumer published in phase k-1
-                const int e = NPROD * (k - 2) + pi, y = e - m;
-                if (y >= 0 && y < H) {
-                    const int vb = kk & 1;               // (k-2) & 1
-                    double dv[5], hv[5];
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        dv[c] = Vb[vb][pi][c][lhi] - Vb[vb][pi][c][llo];
-                        hv[c] = Vb[vb][pi][c][lane];
-                    }
-                    if (writer) {
-                        const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
-                        const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
-#pragma unroll
-                        for (int c = 0; c < 5; c++) D16[t0 + (unsigned)c * XCH * 512u] = dv[c];
-                    }
-                    if (head) {
-#pragma unroll
-                        for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = hv[c];
-                    }
-                }
             }
             __syncthreads();
         }
@@ -456,28 +451,66 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const float* __restrict__ flow,
+__global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const float* __restrict__ flow,
                                            double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
-    __shared__ double xch[4][2][5][64];
+    // Workgroup = one strip = compute wave + store wave (more strips per workgroup only couple them through the barrier).  The compute wave only LOADS: on gfx9-family
+    // hardware loads and stores share one in-order vmcnt, so a wave that also stores D waits, at every
+    // step, for the acknowledgement of stores it issued a step earlier (measured: 126 of 326 us at 320 px).
+    // It publishes the two vsum rows of a step in LDS (double-buffered); after the step's barrier its
+    // store wave forms D = vsum(x+7) - vsum(x-8) from them and writes the tiles, never waiting on memory.
+    __shared__ double xw[2][2][5][64];                  // [buffer][row][channel][lane], 10 KiB
     const int wv = threadIdx.x >> 6;
-    const int wid = blockIdx.x * 4 + wv;
-    if (wid >= npairs * NSTRIP) return;
+    const int wid = blockIdx.x;
+    if (wid >= npairs * NSTRIP) return;                  // both waves of a strip leave together
     const int lane = threadIdx.x & 63;
     const int p = wid / NSTRIP, strip = wid - p * NSTRIP;
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
-    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;   // R[frame p], R[frame p+1]
-    const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
-    const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-    const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
-    const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
-    double (*xw)[5][64] = xch[wv];
-    const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
 
+    if (wv == 1) {
+        const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
+        const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
+        const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+        const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+        const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
+        for (int y0 = 0; y0 < H; y0 += 2) {
+            const int y1 = y0 + 1, buf = (y0 >> 1) & 1;
+            __syncthreads();
+            double d0[5], d1[5], h0[5], h1[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                d0[c] = xw[buf][0][c][lhi] - xw[buf][0][c][llo];
+                d1[c] = xw[buf][1][c][lhi] - xw[buf][1][c][llo];
+                h0[c] = xw[buf][0][c][lane];
+                h1[c] = xw[buf][1][c][lane];
+            }
+            if (writer) {
+                const unsigned sw0 = (unsigned)((x & 7) ^ (y0 & 7)) - (unsigned)(x & 7);   // swizzled slot - plain slot
+                const unsigned sw1 = (unsigned)((x & 7) ^ (y1 & 7)) - (unsigned)(x & 7);
+                const unsigned t0 = dbase + ((unsigned)(y0 >> 6) * 5 * XCH) * 512u + (y0 & 63) * 8 + sw0;
+                const unsigned t1 = dbase + ((unsigned)(y1 >> 6) * 5 * XCH) * 512u + (y1 & 63) * 8 + sw1;
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    D16[t0 + (unsigned)c * XCH * 512u] = d0[c];
+                    D16[t1 + (unsigned)c * XCH * 512u] = d1[c];
+                }
+            }
+            if (head) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    VS0[vbase + (unsigned)((c * H + y0) * 8)] = h0[c];
+                    VS0[vbase + (unsigned)((c * H + y1) * 8)] = h1[c];
+                }
+            }
+        }
+        return;
+    }
+
+    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;   // R[frame p], R[frame p+1]
     float ring[16][5];                                  // rows y-8 .. y+7, slot = row & 15
     double vs[5];
     // software pipeline registers, static slots: inputs of rows r..r+3 in in[(j..j+3)&3], gathered
@@ -500,15 +533,15 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
     ne_gather(R, r1base, in[0], x, m, W, H, plane, g[0]);
     ne_gather(R, r1base, in[1], x, min(m + 1, H - 1), W, H, plane, g[1]);
 
-    // Two rows per step: their normal equations, LDS exchange and stores are independent, only the
-    // five double adds per row chain; pairing the rows inside one basic block lets the scheduler hide
-    // one row's latencies (LDS round trip, dependent f64 adds) behind the other's arithmetic.
+    // Two rows per step: their normal equations are independent, only the five double adds per row chain;
+    // pairing the rows inside one basic block lets the scheduler hide one row's latencies behind the other's
+    // arithmetic.  The step has no branches and no stores, so every s_waitcnt vmcnt is exact.
     for (int yb = 0; yb < H; yb += 16) {
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {
             const int j0 = 2 * jj, j1 = j0 + 1;
             const int y0 = yb + j0, y1 = y0 + 1;
-            if (y0 < H) {                                // H is even; only false in the tail block of H = 40
+            if (H % 16 == 0 || y0 < H) {                 // H is even; only false in the tail block of H = 40
                 const int ra = min(y0 + m, H - 1), rb = min(y1 + m, H - 1);   // entering rows (clamped)
                 float a0[5], a1[5];
                 ne_finish(in[j0 & 3], g[j0 & 1], x, ra, W, H, a0);
@@ -518,46 +551,18 @@ __global__ __launch_bounds__(256) void k_uv(const float* __restrict__ R, const f
                 ne_gather(R, r1base, in[(j1 + 2) & 3], x, min(rb + 2, H - 1), W, H, plane, g[j1 & 1]);
                 ne_load(R, flow, r0base, flbase, x, min(ra + 4, H - 1), W, plane, in[j0 & 3]);
                 ne_load(R, flow, r0base, flbase, x, min(rb + 4, H - 1), W, plane, in[j1 & 3]);
-                double h0[5], h1[5];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
                     const float b0 = y0 >= m + 1 ? ring[(j0 + 8) & 15][c] : ring[0][c];
                     ring[(j0 + m) & 15][c] = a0[c];
                     vs[c] += (double)(a0[c] - b0);
-                    h0[c] = vs[c];
-                    xw[0][c][lane] = vs[c];
+                    xw[jj & 1][0][c][lane] = vs[c];
                     const float b1 = y1 >= m + 1 ? ring[(j1 + 8) & 15][c] : ring[0][c];
                     ring[(j1 + m) & 15][c] = a1[c];
                     vs[c] += (double)(a1[c] - b1);
-                    h1[c] = vs[c];
-                    xw[1][c][lane] = vs[c];
+                    xw[jj & 1][1][c][lane] = vs[c];
                 }
-                __builtin_amdgcn_wave_barrier();
-                double d0[5], d1[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    d0[c] = xw[0][c][lhi] - xw[0][c][llo];
-                    d1[c] = xw[1][c][lhi] - xw[1][c][llo];
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (writer) {
-                    const unsigned sw0 = (unsigned)((x & 7) ^ (y0 & 7)) - (unsigned)(x & 7);   // swizzled slot - plain slot
-                    const unsigned sw1 = (unsigned)((x & 7) ^ (y1 & 7)) - (unsigned)(x & 7);
-                    const unsigned t0 = dbase + ((unsigned)(y0 >> 6) * 5 * XCH) * 512u + (y0 & 63) * 8 + sw0;
-                    const unsigned t1 = dbase + ((unsigned)(y1 >> 6) * 5 * XCH) * 512u + (y1 & 63) * 8 + sw1;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        D16[t0 + (unsigned)c * XCH * 512u] = d0[c];
-                        D16[t1 + (unsigned)c * XCH * 512u] = d1[c];
-                    }
-                }
-                if (head) {
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        VS0[vbase + (unsigned)((c * H + y0) * 8)] = h0[c];
-                        VS0[vbase + (unsigned)((c * H + y1) * 8)] = h1[c];
-                    }
-                }
+                __syncthreads();
             }
         }
     }
@@ -860,7 +865,7 @@ void blur_iteration(const Seg& g, int k, int np)
                            (const float*)g.flow[k], g.vs, g.vs0, np);
     } else {
         const int waves = np * NSTRIP;
-        hipLaunchKernelGGL(k_uv<W>, dim3((waves + 3) / 4), dim3(256), 0, g.stream, (const float*)g.poly[k],
+        hipLaunchKernelGGL(k_uv<W>, dim3(waves), dim3(128), 0, g.stream, (const float*)g.poly[k],
                            (const float*)g.flow[k], g.vs, g.vs0, np);
     }
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,

@@ -56,6 +56,84 @@ __global__ __launch_bounds__(64 * WAVES) void read_tiles(const double* __restric
     if (acc.x + acc.y == 12345.678) out[0] = acc.x;
 }
 
+// k_uv's D-write pattern.  MODE 0 (as shipped): per 2 rows, 10 stores of 8 B per lane, 8 lanes = one 64-B half line,
+// every 8-lane group in another tile.  MODE 1: per 8 rows, 15 stores of 16 B per lane, 32 lanes = 512 contiguous bytes.
+template <int MODE>
+__global__ __launch_bounds__(256) void write_uv(double* __restrict__ D)
+{
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= kPairs * 7) return;
+    const int p = wid / 7, strip = wid - p * 7;
+    const int64_t pairbase = (int64_t)p * kPairTiles * 512;
+    if (MODE == 0) {
+        const int xl = strip * 48 - 8 + lane;
+        const bool writer = lane >= 8 && lane < 56 && xl < 320;
+        const int x = min(max(xl, 0), 319);
+        for (int y0 = 0; y0 < 320; y0 += 2)
+            if (writer)
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int y = y0 + r;
+                        D[pairbase + ((int64_t)(y >> 6) * 5 * kXch + c * kXch + (x >> 3)) * 512 + (y & 63) * 8 + ((x & 7) ^ (y & 7))] = 1.0 + y;
+                    }
+    } else {
+        const int ntile = strip == 6 ? 4 : 6;
+        for (int yb = 0; yb < 320; yb += 8)
+#pragma unroll
+            for (int i = 0; i < 15; i++) {
+                const int e = i * 128 + lane * 2, c = e / 384, rem = e - c * 384, tile = rem >> 6, within = rem & 63;
+                if (tile < ntile)
+                    *reinterpret_cast<dbl2*>(D + pairbase + ((int64_t)(yb >> 6) * 5 * kXch + c * kXch + strip * 6 + tile) * 512 +
+                                             (yb & 63) * 8 + within) = dbl2{1.0 + yb, 2.0};
+            }
+    }
+}
+
+// k_uv's whole traffic without its arithmetic: per row and lane R0 (5 floats), the two R1 gather rows (10 floats
+// each, at the unwarped position), flow (2 floats) in; D (5 doubles, tile pattern) out.  UNR rows in flight.
+struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
+struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+template <int UNR, bool STORE>
+__global__ __launch_bounds__(256) void uv_traffic(const float* __restrict__ R, const float* __restrict__ flow, double* __restrict__ D)
+{
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= kPairs * 7) return;
+    const int p = wid / 7, strip = wid - p * 7;
+    const int xl = strip * 48 - 8 + lane;
+    const bool writer = lane >= 8 && lane < 56 && xl < 320;
+    const int x = min(max(xl, 0), 318);
+    const int64_t pairbase = (int64_t)p * kPairTiles * 512;
+    const float* R0 = R + (int64_t)p * 5 * 102400; const float* R1 = R0 + 5 * 102400;
+    const float* fl = flow + (int64_t)p * 2 * 102400;
+    float acc = 0.f;
+    for (int y0 = 0; y0 < 320; y0 += UNR) {
+        F4 a[UNR], t0[UNR], t1[UNR], b0[UNR], b1[UNR]; F2 t2[UNR], b2[UNR]; float a4[UNR], dx[UNR], dy[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+            const int y = min(y0 + r, 318), o = y * 320 + x;
+            dx[r] = fl[o]; dy[r] = fl[102400 + o];
+            const float* q = R0 + o * 5; a[r] = *(const F4*)q; a4[r] = q[4];
+            const float* g = R1 + o * 5;
+            t0[r] = *(const F4*)g; t1[r] = *(const F4*)(g + 4); t2[r] = *(const F2*)(g + 8);
+            b0[r] = *(const F4*)(g + 1600); b1[r] = *(const F4*)(g + 1604); b2[r] = *(const F2*)(g + 1608);
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+            const float v = dx[r] + dy[r] + a[r].a + a[r].d + a4[r] + t0[r].a + t1[r].b + t2[r].a + b0[r].c + b1[r].d + b2[r].b;
+            acc += v;
+            if (STORE && writer) {
+                const int y = y0 + r;
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    D[pairbase + ((int64_t)(y >> 6) * 5 * kXch + c * kXch + (x >> 3)) * 512 + (y & 63) * 8 + ((x & 7) ^ (y & 7))] = v + c;
+            }
+        }
+    }
+    if (acc == 12345.678f) D[0] = acc;
+}
+
 template <typename F>
 static void timeit(const char* name, double bytes, F launch)
 {
@@ -95,5 +173,34 @@ int main()
     timeit("tiles [xc][c] depth4 1 wave", bytes, [&] { read_tiles<1, 4, 1><<<nb, 64>>>(a, out); });
     timeit("tiles [xc][c] depth2 2 waves", bytes, [&] { read_tiles<1, 2, 2><<<nb, 128>>>(a, out); });
     timeit("tiles [xc][c] depth2 4 waves", bytes, [&] { read_tiles<1, 2, 4><<<nb, 256>>>(a, out); });
+    timeit("k_uv D writes: 8 B/lane, 128 B per tile per step", bytes, [&] { write_uv<0><<<(kPairs * 7 + 3) / 4, 256>>>(b); });
+    timeit("k_uv D writes: 16 B/lane, 512 B per tile per flush", bytes, [&] { write_uv<1><<<(kPairs * 7 + 3) / 4, 256>>>(b); });
+    {
+        float *R, *fl;
+        hipMalloc(&R, (size_t)(kPairs + 1) * 5 * 102400 * 4); hipMalloc(&fl, (size_t)kPairs * 2 * 102400 * 4);
+        hipMemset(R, 0, (size_t)(kPairs + 1) * 5 * 102400 * 4); hipMemset(fl, 0, (size_t)kPairs * 2 * 102400 * 4);
+        const double rd = (double)kPairs * 102400 * (20 + 40 + 8), wr = (double)kPairs * 102400 * 40;
+        const int nb = (kPairs * 7 + 3) / 4;
+        timeit("k_uv traffic, loads only, 2 rows in flight", rd, [&] { uv_traffic<2, false><<<nb, 256>>>(R, fl, b); });
+        timeit("k_uv traffic, loads only, 4 rows in flight", rd, [&] { uv_traffic<4, false><<<nb, 256>>>(R, fl, b); });
+        timeit("k_uv traffic, loads only, 8 rows in flight", rd, [&] { uv_traffic<8, false><<<nb, 256>>>(R, fl, b); });
+        {
+            hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
+            hipEvent_t e0, e1, e2; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+            for (int rep = 0; rep < 3; rep++) {
+                hipDeviceSynchronize();
+                hipEventRecord(e0, s1); hipStreamWaitEvent(s2, e0, 0);
+                uv_traffic<4, false><<<nb, 256, 0, s1>>>(R, fl, b);
+                write_uv<0><<<nb, 256, 0, s2>>>(a);
+                hipEventRecord(e2, s2); hipStreamWaitEvent(s1, e2, 0);
+                hipEventRecord(e1, s1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("loads (4 rows in flight) and D stores as two concurrent kernels: %8.1f us  %6.2f TB/s\n", ms * 1e3, (rd + wr) / (ms * 1e-3) / 1e12);
+            }
+        }
+        timeit("k_uv traffic, loads + D stores, 2 rows in flight", rd + wr, [&] { uv_traffic<2, true><<<nb, 256>>>(R, fl, b); });
+        timeit("k_uv traffic, loads + D stores, 4 rows in flight", rd + wr, [&] { uv_traffic<4, true><<<nb, 256>>>(R, fl, b); });
+        timeit("k_uv traffic, loads + D stores, 8 rows in flight", rd + wr, [&] { uv_traffic<8, true><<<nb, 256>>>(R, fl, b); });
+    }
     return 0;
 }
