@@ -218,7 +218,7 @@ class Context:
 
     def stage_ms(self):
         out = []
-        for i in range(4):
+        for i in range(6):
             ms = C.c_float()
             self._check(self._L.avd_stage_ms(self._h, i, C.byref(ms)))
             out.append(float(ms.value))

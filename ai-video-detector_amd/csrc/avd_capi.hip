@@ -293,6 +293,7 @@ int avd_create(int device_id, avd_ctx** out)
               hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
+    for (int i = 0; ok && i < 12; i++) ok = hipEventCreate(&ctx->kern_ev[i]) == hipSuccess;
     if (ok) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
@@ -317,6 +318,7 @@ void avd_destroy(avd_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->kern_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -410,6 +412,13 @@ int avd_synchronize(avd_ctx* ctx)
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->stage_ev[i], ctx->stage_ev[i + 1]) == hipSuccess) ctx->stage_ms[i] = ms;
         }
+        // 4 / 5: mean duration of one k_uv<320> / k_hscan<320> launch (first segment of the last chunk)
+        float sum[2] = {0.f, 0.f}; int cnt[2] = {0, 0};
+        for (int i = 0; i + 1 < ctx->kern_ev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->kern_ev[i], ctx->kern_ev[i + 1]) == hipSuccess) { sum[(i >> 1) & 1] += ms; cnt[(i >> 1) & 1]++; }
+        }
+        for (int k = 0; k < 2; k++) ctx->stage_ms[4 + k] = cnt[k] ? sum[k] / cnt[k] : 0.f;
     }
     return AVD_OK;
 }
@@ -447,7 +456,7 @@ int avd_set_profiling(avd_ctx* ctx, int enable)
 
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms)
 {
-    if (!ctx || !ms || stage < 0 || stage > 3) return AVD_ERR_ARG;
+    if (!ctx || !ms || stage < 0 || stage > 5) return AVD_ERR_ARG;
     *ms = ctx->stage_ms[stage];
     return AVD_OK;
 }
@@ -471,6 +480,7 @@ int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_by
     else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)n * (AVD_NPIX >> (2 * k)) * 4; }
     else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)n * 5 * (AVD_NPIX >> (2 * k)) * 4; }
     else if ((k = level("flow")) >= 0) { src = ws.d_flow[k]; bytes = (size_t)std::max(n - 1, 0) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if (std::strcmp(name, "vs0") == 0) { src = ws.d_vs0; bytes = (size_t)128 * 5 * AVD_SMALL * 8 * 8; }
     else { ctx->err = "unknown debug buffer"; return AVD_ERR_ARG; }
     if (!src) { ctx->err = "buffer not allocated yet"; return AVD_ERR_ARG; }
     bytes = std::min(bytes, out_bytes);

@@ -334,91 +334,119 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
 // software-pipeline their own entries (stride NPROD rows): flow/R0 loads three phases ahead, gathers
 // one phase ahead, static register slots; their steps have no branches around memory operations.
 // ---------------------------------------------------------------------------------------
+#ifdef AVD_STAMPS
+#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+constexpr unsigned kStampOff = 127u * 5u * 320u * 8u;      // pair 127's VS0 region (unused below 128 pairs)
+#endif
 template <int W, int NPROD>
 __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
                                                            double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
-    static_assert(NPROD == 3 || NPROD == 4, "ring / unroll constants below cover 3 or 4 producers");
+    static_assert(NPROD == 3 || NPROD == 4, "ring size below covers 3 or 4 producers");
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
-    constexpr int RS = NPROD == 4 ? 16 : 18;             // register ring of the consumer: >= 16 rows, multiple of NPROD
-    constexpr int U = NPROD == 4 ? 4 : 12;               // phases per unrolled body: multiple of RS/NPROD and of 4 (producer slots)
+    constexpr int RSL = 24;                              // M-row ring in LDS: 15 rows of history + two phases of producer lead, multiple of NPROD
+    constexpr int U = 4;                                 // phases per unrolled body (static producer register slots)
     constexpr int NE = H + m;                            // entries
     constexpr int NP = (NE + NPROD - 1) / NPROD;         // producing phases
     constexpr int NPH = ((NP + 1 + U - 1) / U) * U;      // loop trip count (drain + round up to the unroll)
-    __shared__ float Mb[2][NPROD][5][64];
-    __shared__ double Vb[5][64];
+    __shared__ float ringM[RSL][5][64];                  // normal-equation rows, slot = entry % RSL (30 KiB)
+    __shared__ double Vb[NPROD][5][64];                  // the consumer's own exchange rows (wave-private)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = blockIdx.x / NSTRIP, strip = blockIdx.x - p * NSTRIP;
+    // workgroups are dealt round-robin to the 8 XCDs; the strips of a pair share their halo columns and the
+    // gathered R1 rows, so all strips of a pair go to one XCD (one L2): ~20 % fewer bytes fetched
+    const int sj = blockIdx.x >> 3;
+    const int p = (blockIdx.x & 7) + 8 * (sj / NSTRIP), strip = sj % NSTRIP;
+    if (p >= npairs) return;
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
     if (wave == 0) {
         // ------------------------------- consumer -------------------------------------------
+        // Stamped (s_memtime), this wave is the critical path of the workgroup, so a phase's NPROD rows are
+        // handled in passes: all LDS reads first, then the sequential double adds, then ONE exchange of
+        // the vsum rows (+7 / -8 lanes) and the stores.  Nothing but vs[] lives across phases.
         const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
         const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
         const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
         const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
         const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
-        float ring[RS][5];
         double vs[5] = {0, 0, 0, 0, 0};
-        for (int kb = 0; kb < NPH; kb += U) {
+#ifdef AVD_STAMPS
+        unsigned long long cs0, cs1, cs2, csA = 0, csC = 0;
+#endif
+        for (int k = 0; k < NPH; k++) {                  // consumes the entries produced in phase k-1
+#ifdef AVD_STAMPS
+            STAMP(cs0);
+#endif
+            if (k >= 1 && k - 1 < NP) {
+                const int e0 = NPROD * (k - 1);
+                if (e0 + NPROD <= m) {
+                    // entries 0..m-1 only fill the box; nothing to do until the last of them is in
+                } else if (e0 < m) {
+                    // the phase that completes the initial box: vs = (m+2) * row 0 + rows 1..m-1, in that order
 #pragma unroll
-            for (int kk = 0; kk < U; kk++) {
-                const int k = kb + kk;                   // consumes the entries produced in phase k-1
-                if (k >= 1 && k - 1 < NP) {
-                    const int kp = (kk + U - 1) % U;     // (k-1) mod U, static
+                    for (int c = 0; c < 5; c++) {
+                        vs[c] = (double)(ringM[0][c][lane] * (float)(m + 2));
 #pragma unroll
-                    for (int i = 0; i < NPROD; i++) {
-                        const int e = NPROD * (k - 1) + i;
-                        const int es = (NPROD * kp + i) % RS;      // e mod RS, static (NPROD*U is a multiple of RS)
-                        if (e < NE) {
-                            float a[5];
+                        for (int r = 1; r < m; r++) vs[c] += (double)ringM[r][c][lane];
+                    }
+                }
+                float a[NPROD][5], b[NPROD][5];
 #pragma unroll
-                            for (int c = 0; c < 5; c++) a[c] = Mb[kp & 1][i][c][lane];
-                            if (e < m) {
+                for (int i = 0; i < NPROD; i++) {
+                    const int e = e0 + i, y = e - m;
+                    const int sa = e % RSL, sb = y >= m + 1 ? (e - 15) % RSL : 0;     // row y-8 = entry e-15
 #pragma unroll
-                                for (int c = 0; c < 5; c++) ring[es][c] = a[c];
-                                if (e == m - 1) {
+                    for (int c = 0; c < 5; c++) { a[i][c] = ringM[sa][c][lane]; b[i][c] = ringM[sb][c][lane]; }
+                }
 #pragma unroll
-                                    for (int c = 0; c < 5; c++) {
-                                        vs[c] = (double)(ring[0][c] * (float)(m + 2));
+                for (int i = 0; i < NPROD; i++) {
+                    const int e = e0 + i;
+                    if (e >= m && e < NE) {
 #pragma unroll
-                                        for (int r = 1; r < m; r++) vs[c] += (double)ring[r][c];
-                                    }
-                                }
-                            } else {
-                                const int y = e - m;
-#pragma unroll
-                                for (int c = 0; c < 5; c++) {
-                                    const float b = y >= m + 1 ? ring[(es + RS - 15) % RS][c] : ring[0][c];   // row y-8 = e-15
-                                    ring[es][c] = a[c];
-                                    vs[c] += (double)(a[c] - b);
-                                    Vb[c][lane] = vs[c];
-                                }
-                                __builtin_amdgcn_wave_barrier();
-                                double dv[5];
-#pragma unroll
-                                for (int c = 0; c < 5; c++) dv[c] = Vb[c][lhi] - Vb[c][llo];
-                                __builtin_amdgcn_wave_barrier();
-                                if (writer) {
-                                    const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
-                                    const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
-#pragma unroll
-                                    for (int c = 0; c < 5; c++) D16[t0 + (unsigned)c * XCH * 512u] = dv[c];
-                                }
-                                if (head) {
-#pragma unroll
-                                    for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = vs[c];
-                                }
-                            }
+                        for (int c = 0; c < 5; c++) {
+                            vs[c] += (double)(a[i][c] - b[i][c]);
+                            Vb[i][c][lane] = vs[c];
                         }
                     }
                 }
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
+                double dv[NPROD][5];
+#pragma unroll
+                for (int i = 0; i < NPROD; i++)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) dv[i][c] = Vb[i][c][lhi] - Vb[i][c][llo];
+#pragma unroll
+                for (int i = 0; i < NPROD; i++) {
+                    const int e = e0 + i, y = e - m;
+                    if (e >= m && e < NE) {
+                        if (writer) {
+                            const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
+                            const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
+#pragma unroll
+                            for (int c = 0; c < 5; c++) D16[t0 + (unsigned)c * XCH * 512u] = dv[i][c];
+                        }
+                        if (head) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = Vb[i][c][lane];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
+#ifdef AVD_STAMPS
+            STAMP(cs1);
+#endif
+            __syncthreads();
+#ifdef AVD_STAMPS
+            STAMP(cs2); csA += cs1 - cs0; csC += cs2 - cs1;
+#endif
         }
+#ifdef AVD_STAMPS
+        if (W == 160 && blockIdx.x == 200 && lane == 0) { VS0[kStampOff + 0] = (double)csA; VS0[kStampOff + 1] = (double)csC; VS0[kStampOff + 2] = (double)NPH; }
+#endif
         return;
     }
 
@@ -430,24 +458,48 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
 #pragma unroll
     for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
     ne_gather(R, r1base, in[0], x, row_of(0), W, H, plane, g[0]);
+#ifdef AVD_STAMPS
+    unsigned long long ps0, ps1, ps2, ps3, ps4, psW = 0, psA = 0, psB = 0, psC = 0;
+#endif
     for (int kb = 0; kb < NPH; kb += U) {
 #pragma unroll
         for (int kk = 0; kk < U; kk++) {
             const int k = kb + kk;
+#ifdef AVD_STAMPS
+            STAMP(ps0);
+            __builtin_amdgcn_s_waitcnt(0x0F74);          // vmcnt(4): the six gather loads of the previous phase are back
+            STAMP(ps1);
+#endif
             if (k < NP) {
                 // rows past the last entry (e >= NE, only in the final phase) are evaluated on clamped
                 // addresses and never consumed: no branch around the loads
                 float a[5];
                 ne_finish(in[kk & 3], g[kk & 1], x, row_of(k), W, H, a);
+                const int slot = (NPROD * k + pi) % RSL;
 #pragma unroll
-                for (int c = 0; c < 5; c++) Mb[kk & 1][pi][c][lane] = a[c];
+                for (int c = 0; c < 5; c++) ringM[slot][c][lane] = a[c];
+#ifdef AVD_STAMPS
+                STAMP(ps2);
+#endif
                 // refill: gathers of this wave's next entry, inputs three entries ahead
                 ne_gather(R, r1base, in[(kk + 1) & 3], x, row_of(k + 1), W, H, plane, g[(kk + 1) & 1]);
                 ne_load(R, flow, r0base, flbase, x, row_of(k + 3), W, plane, in[(kk + 3) & 3]);
             }
+#ifdef AVD_STAMPS
+            STAMP(ps3);
+#endif
             __syncthreads();
+#ifdef AVD_STAMPS
+            STAMP(ps4);
+            if (k < NP) { psW += ps1 - ps0; psA += ps2 - ps1; psB += ps3 - ps2; psC += ps4 - ps3; }
+#endif
         }
     }
+#ifdef AVD_STAMPS
+    if (W == 160 && blockIdx.x == 200 && lane == 0 && pi == 0) {
+        VS0[kStampOff + 8] = (double)psW; VS0[kStampOff + 9] = (double)psA; VS0[kStampOff + 10] = (double)psB; VS0[kStampOff + 11] = (double)psC;
+    }
+#endif
 }
 
 template <int W>
@@ -463,11 +515,14 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
     // It publishes the two vsum rows of a step in LDS (double-buffered); after the step's barrier its
     // store wave forms D = vsum(x+7) - vsum(x-8) from them and writes the tiles, never waiting on memory.
     __shared__ double xw[2][2][5][64];                  // [buffer][row][channel][lane], 10 KiB
+    __shared__ float ringl[16][5][64];                  // the compute wave's last 16 evaluated rows, slot = row & 15
     const int wv = threadIdx.x >> 6;
-    const int wid = blockIdx.x;
-    if (wid >= npairs * NSTRIP) return;                  // both waves of a strip leave together
     const int lane = threadIdx.x & 63;
-    const int p = wid / NSTRIP, strip = wid - p * NSTRIP;
+    // all strips of a pair on one XCD (see k_uvp)
+    const int sj = blockIdx.x >> 3;
+    const bool remap = !(npairs & 0x10000); npairs &= 0xffff;
+    const int p = remap ? (blockIdx.x & 7) + 8 * (sj / NSTRIP) : blockIdx.x / NSTRIP, strip = remap ? sj % NSTRIP : blockIdx.x % NSTRIP;
+    if (p >= npairs) return;                             // both waves of a strip leave together
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
@@ -511,59 +566,64 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
     }
 
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;   // R[frame p], R[frame p+1]
-    float ring[16][5];                                  // rows y-8 .. y+7, slot = row & 15
+    // Software pipeline, static register slots, FOUR steps deep: a row's evaluation needs two dependent
+    // memory round trips (flow/R0, then the gather of R1 at the warped position), and under load one round
+    // trip takes about as long as two steps.  At the step that consumes rows (r, r+1) the gathers of rows
+    // r+4, r+5 and the flow/R0 loads of rows r+8, r+9 are issued.  The 16-row history of the box filter
+    // lives in LDS (20 KiB), which is what leaves registers for in[8] and g[4].
+    NeIn in[8]; NeG g[4];
     double vs[5];
-    // software pipeline registers, static slots: inputs of rows r..r+3 in in[(j..j+3)&3], gathered
-    // neighbours of rows r, r+1 in g[j&1], g[(j+1)&1]  (j = step index mod 16, r = entering row)
-    NeIn in[4]; NeG g[2];
 #pragma unroll
     for (int r = 0; r < m; r++) {
+        float a[5];
         ne_load(R, flow, r0base, flbase, x, r, W, plane, in[0]);
         ne_gather(R, r1base, in[0], x, r, W, H, plane, g[0]);
-        ne_finish(in[0], g[0], x, r, W, H, ring[r]);
+        ne_finish(in[0], g[0], x, r, W, H, a);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            ringl[r][c][lane] = a[c];
+            if (r == 0) vs[c] = (double)(a[c] * (float)(m + 2));
+            else vs[c] += (double)a[c];
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
-        vs[c] = (double)(ring[0][c] * (float)(m + 2));
+    for (int k = 0; k < 8; k++) ne_load(R, flow, r0base, flbase, x, min(m + k, H - 1), W, plane, in[k]);
 #pragma unroll
-        for (int r = 1; r < m; r++) vs[c] += (double)ring[r][c];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) ne_load(R, flow, r0base, flbase, x, min(m + k, H - 1), W, plane, in[k]);
-    ne_gather(R, r1base, in[0], x, m, W, H, plane, g[0]);
-    ne_gather(R, r1base, in[1], x, min(m + 1, H - 1), W, H, plane, g[1]);
+    for (int k = 0; k < 4; k++) ne_gather(R, r1base, in[k], x, min(m + k, H - 1), W, H, plane, g[k]);
 
-    // Two rows per step: their normal equations are independent, only the five double adds per row chain;
-    // pairing the rows inside one basic block lets the scheduler hide one row's latencies behind the other's
-    // arithmetic.  The step has no branches and no stores, so every s_waitcnt vmcnt is exact.
-    for (int yb = 0; yb < H; yb += 16) {
+    // Two rows per step: their normal equations are independent, only the five double adds per row chain.
+    // The step has no branches and no stores, so every s_waitcnt vmcnt is exact.
+    static_assert(H % 8 == 0, "four steps per unrolled body");
+    for (int yb = 0; yb < H; yb += 8) {
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
+        for (int jj = 0; jj < 4; jj++) {
             const int j0 = 2 * jj, j1 = j0 + 1;
             const int y0 = yb + j0, y1 = y0 + 1;
-            if (H % 16 == 0 || y0 < H) {                 // H is even; only false in the tail block of H = 40
-                const int ra = min(y0 + m, H - 1), rb = min(y1 + m, H - 1);   // entering rows (clamped)
-                float a0[5], a1[5];
-                ne_finish(in[j0 & 3], g[j0 & 1], x, ra, W, H, a0);
-                ne_finish(in[j1 & 3], g[j1 & 1], x, rb, W, H, a1);
-                // refill the slots just consumed: gathers of rows r+2, inputs of rows r+4
-                ne_gather(R, r1base, in[(j0 + 2) & 3], x, min(ra + 2, H - 1), W, H, plane, g[j0 & 1]);
-                ne_gather(R, r1base, in[(j1 + 2) & 3], x, min(rb + 2, H - 1), W, H, plane, g[j1 & 1]);
-                ne_load(R, flow, r0base, flbase, x, min(ra + 4, H - 1), W, plane, in[j0 & 3]);
-                ne_load(R, flow, r0base, flbase, x, min(rb + 4, H - 1), W, plane, in[j1 & 3]);
+            const int ra = min(y0 + m, H - 1), rb = min(y1 + m, H - 1);   // entering rows (clamped)
+            float a0[5], a1[5];
+            ne_finish(in[j0], g[j0 & 3], x, ra, W, H, a0);
+            ne_finish(in[j1], g[j1 & 3], x, rb, W, H, a1);
+            // refill the slots just consumed: gathers two steps ahead, inputs four steps ahead
+            ne_gather(R, r1base, in[(j0 + 4) & 7], x, min(ra + 4, H - 1), W, H, plane, g[j0 & 3]);
+            ne_gather(R, r1base, in[(j1 + 4) & 7], x, min(rb + 4, H - 1), W, H, plane, g[j1 & 3]);
+            ne_load(R, flow, r0base, flbase, x, min(ra + 8, H - 1), W, plane, in[j0]);
+            ne_load(R, flow, r0base, flbase, x, min(rb + 8, H - 1), W, plane, in[j1]);
+            // leaving rows y-8 (row 0 while the window still touches the top edge); read both before the
+            // entering rows overwrite their slots (row y1+7 takes the slot of row y0-8)
+            const int so0 = y0 >= m + 1 ? (y0 + 8) & 15 : 0, so1 = y1 >= m + 1 ? (y1 + 8) & 15 : 0;
+            float b0[5], b1[5];
 #pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const float b0 = y0 >= m + 1 ? ring[(j0 + 8) & 15][c] : ring[0][c];
-                    ring[(j0 + m) & 15][c] = a0[c];
-                    vs[c] += (double)(a0[c] - b0);
-                    xw[jj & 1][0][c][lane] = vs[c];
-                    const float b1 = y1 >= m + 1 ? ring[(j1 + 8) & 15][c] : ring[0][c];
-                    ring[(j1 + m) & 15][c] = a1[c];
-                    vs[c] += (double)(a1[c] - b1);
-                    xw[jj & 1][1][c][lane] = vs[c];
-                }
-                __syncthreads();
+            for (int c = 0; c < 5; c++) { b0[c] = ringl[so0][c][lane]; b1[c] = ringl[so1][c][lane]; }
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                ringl[(y0 + m) & 15][c][lane] = a0[c];
+                ringl[(y1 + m) & 15][c][lane] = a1[c];
+                vs[c] += (double)(a0[c] - b0[c]);
+                xw[jj & 1][0][c][lane] = vs[c];
+                vs[c] += (double)(a1[c] - b1[c]);
+                xw[jj & 1][1][c][lane] = vs[c];
             }
+            __syncthreads();
         }
     }
 }
@@ -810,6 +870,7 @@ struct Seg {
     float* flow[AVD_FB_LEVELS];
     double *vs, *vs0;
     float *stats, *part, *flow_il;
+    avd_ctx* prof;                       // non-null: record kernel events of the full-resolution blur launches
 };
 
 static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_off)
@@ -824,6 +885,7 @@ static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_of
         g.poly[k] = ws.d_poly[k] + (size_t)frame_off * 5 * plane;
         g.flow[k] = ws.d_flow[k] + (size_t)pair_off * 2 * plane;
     }
+    g.prof = ctx->profiling && pair_off == 0 ? ctx : nullptr;
     g.vs = ws.d_vs + (size_t)pair_off * (5 * AVD_NPIX + 512);
     g.vs0 = ws.d_vs0 + (size_t)pair_off * 5 * S * 8;
     g.stats = ws.d_stats + (size_t)pair_off * 2;
@@ -857,19 +919,28 @@ void blur_iteration(const Seg& g, int k, int np)
     // 2 (default) = k_uvp<4> below full resolution (issue-bound levels), k_uv at 320x320 (bandwidth-bound),
     // 3 = k_uvp<3 producers> everywhere, 4 = k_uvp<3> at 320x320 + k_uvp<4> below
     static const int variant = [] { const char* e = std::getenv("AVD_UV_VARIANT"); return e ? std::atoi(e) : 2; }();
+    // profiling: HIP events around the two full-resolution kernels (avd_stage_ms 4 and 5)
+    auto mark = [&](void) {
+        if (W == S && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], g.stream);
+    };
+    mark();
+    const int grid = 8 * ((np + 7) / 8) * NSTRIP;        // (XCD, pair-in-XCD, strip); pairs >= np exit at once
+    static const int noremap = [] { const char* e = std::getenv("AVD_NOREMAP"); return e ? std::atoi(e) : 0; }();
+    const int npx = np | (noremap ? 0x10000 : 0);
     if (variant == 3 || (variant == 4 && W == S)) {
-        hipLaunchKernelGGL((k_uvp<W, 3>), dim3(np * NSTRIP), dim3(256), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
+        hipLaunchKernelGGL((k_uvp<W, 3>), dim3(grid), dim3(256), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, npx);
     } else if (variant == 1 || ((variant == 2 || variant == 4) && W < S)) {
-        hipLaunchKernelGGL((k_uvp<W, 4>), dim3(np * NSTRIP), dim3(320), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
+        hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(320), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, npx);
     } else {
-        const int waves = np * NSTRIP;
-        hipLaunchKernelGGL(k_uv<W>, dim3(waves), dim3(128), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
+        hipLaunchKernelGGL(k_uv<W>, dim3(grid), dim3(128), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, npx);
     }
+    mark(); mark();
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,
                        (const double*)g.vs0, g.flow[k], np);
+    mark();
 }
 
 }  // namespace
@@ -880,6 +951,7 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
 {
     if (n < 2) return 0;
     const Seg g = make_seg(ctx, stream, frame_off, pair_off);
+    if (g.prof) ctx->kern_ev_used = 0;
     const int np = n - 1;
     pyramid_level<3>(ctx, g, d_small, n);
     pyramid_level<2>(ctx, g, d_small, n);

@@ -108,8 +108,10 @@ struct avd_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t stage_ev[5] = {};
+    hipEvent_t kern_ev[12] = {};           // profiling: start/stop of the 3 k_uv<320> and 3 k_hscan<320> launches of a segment
+    int kern_ev_used = 0;
     int profiling = 0;
-    float stage_ms[4] = {};
+    float stage_ms[6] = {};
     std::string err;
     Workspace ws;
     FbConsts fbc;

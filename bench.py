@@ -38,17 +38,35 @@ def algorithmic_bytes_per_frame(h, w):
     return h * w * 3 + 320 * 320 + 1024 + 16
 
 
-def farneback_model(n_frames, stage_ms):
-    """Second-largest view of the step: the Farneback stage (all pairs of the clip, 4 pyramid scales, 3
-    iterations).  'design_traffic' = bytes the two-kernel blur moves by construction per pixel and
-    iteration (D written + read back in double 80 B, R0 + R1 40 B, flow in + out 16 B); flop count from the
-    operation list in DESIGN.md 4.3 (~73 Mflop per pair).  It is bandwidth/latency bound, far from the
-    vector-FP32 roofline."""
+def farneback_model(n_frames, stage_ms, uv_ms, hscan_ms, ms_per_step):
+    """The Farneback stage (all pairs of the clip, 4 pyramid scales, 3 iterations) and its two dominant
+    kernels at 320x320, timed live with HIP events around each launch (avd_stage_ms 4 / 5).
+    Algorithmic bytes per pixel and launch: k_uv reads R0 and R1 (5 floats each) and the
+    flow (2 floats) and writes D (5 doubles) = 88 B; k_hscan reads D and writes the flow = 48 B.
+    'traffic' = HBM bytes per launch from the committed PMC passes (profiles/r01_farneback_pmc.json).
+    Stage level: 'design_traffic' = 136 B per pixel and iteration over all four scales; flop count from the
+    operation list in DESIGN.md 4.3 (~73 Mflop per pair): far from the vector-FP32 roofline."""
     pairs, px = max(n_frames - 1, 0), 320 * 320 + 160 * 160 + 80 * 80 + 40 * 40
+    pmc = {}
+    pmc_file = os.path.join(ROOT, "profiles", "r01_farneback_pmc.json")
+    if os.path.exists(pmc_file) and n_frames == 120:
+        with open(pmc_file) as fh:
+            pmc = json.load(fh).get("kernels", {})
+
+    def kernel(name, what, bytes_px, ms, launches):
+        alg = pairs * 320 * 320 * bytes_px
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": what, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc.get(name, {}).get("hbm_bytes"),
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(ms, 4), "launches_per_step": launches,
+                "share_of_step": round(launches * ms / ms_per_step, 4) if ms_per_step > 0 else 0.0}
+
     traffic = pairs * px * 3 * 136
     flops = pairs * 73e6
     t = stage_ms * 1e-3
     return {"stage": "Farneback + flow statistics", "avg_ms": round(stage_ms, 4), "bound": "hbm",
+            "k_uv_320": kernel("k_uv<320>", "k_uv<320> (normal equations fused with the vertical double running sums)", 88, uv_ms, 3),
+            "k_hscan_320": kernel("k_hscan<320>", "k_hscan<320> (horizontal double running sums + 2x2 solve)", 48, hscan_ms, 3),
             "design_traffic_bytes": traffic, "achieved": round(traffic / t / 1e9, 1) if t > 0 else 0.0,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
             "flops": flops, "tflops": round(flops / t / 1e12, 2) if t > 0 else 0.0, "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF}
@@ -143,7 +161,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    stage = np.zeros(4)
+    stage = np.zeros(6)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -184,7 +202,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(pre_ms, 4),
                          "share_of_step": round(pre_ms / ms_per_step, 4)},
-            "roofline_farneback": farneback_model(n, float(stage[2])),
+            "roofline_farneback": farneback_model(n, float(stage[2]), float(stage[4]), float(stage[5]), ms_per_step),
             "stages_ms": {"preprocess": round(float(stage[0]), 4), "hash_hamming_records": round(float(stage[1]), 4),
                           "farneback_and_flow_stats": round(float(stage[2]), 4), "records_copy_out": round(float(stage[3]), 4)},
             "result_check": {"ai_timeline_head": [round(v, 6) for v in result["timeline"][:3]],

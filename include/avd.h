@@ -108,7 +108,9 @@ int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
 /* Per-stage device time (ms, HIP events on ctx's stream) of the LAST avd_analyze_frames*
  * call when profiling was enabled with avd_set_profiling(ctx, 1): stage 0 = fused
  * preprocess kernel (+ the 2 KB moment memset), 1 = hash / Hamming / record kernels,
- * 2 = Farneback (pyramid .. flow) + flow statistics, 3 = records copy-out. */
+ * 2 = Farneback (pyramid .. flow) + flow statistics, 3 = records copy-out; 4 / 5 = mean duration of
+ * ONE launch of the two dominant Farneback kernels at 320x320 (vertical-sum kernel k_uv / horizontal
+ * scan k_hscan; three launches each per call, events around each launch). */
 int avd_set_profiling(avd_ctx* ctx, int enable);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 

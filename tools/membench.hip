@@ -134,6 +134,44 @@ __global__ __launch_bounds__(256) void uv_traffic(const float* __restrict__ R, c
     if (acc == 12345.678f) D[0] = acc;
 }
 
+// loads two rows at a time (as uv_traffic<2>), but the D stores of SB rows leave together in one burst
+template <int SB>
+__global__ __launch_bounds__(256) void uv_burst(const float* __restrict__ R, const float* __restrict__ flow, double* __restrict__ D)
+{
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= kPairs * 7) return;
+    const int p = wid / 7, strip = wid - p * 7;
+    const int xl = strip * 48 - 8 + lane;
+    const bool writer = lane >= 8 && lane < 56 && xl < 320;
+    const int x = min(max(xl, 0), 318);
+    const int64_t pairbase = (int64_t)p * kPairTiles * 512;
+    const float* R0 = R + (int64_t)p * 5 * 102400; const float* R1 = R0 + 5 * 102400;
+    const float* fl = flow + (int64_t)p * 2 * 102400;
+    for (int yb = 0; yb < 320; yb += SB) {
+        float vrow[SB];
+#pragma unroll
+        for (int y0 = 0; y0 < SB; y0 += 2) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int y = min(yb + y0 + r, 318), o = y * 320 + x;
+                const float* q = R0 + o * 5; const float* g = R1 + o * 5;
+                const F4 a = *(const F4*)q, t0 = *(const F4*)g, t1 = *(const F4*)(g + 4), b0 = *(const F4*)(g + 1600), b1 = *(const F4*)(g + 1604);
+                const F2 t2 = *(const F2*)(g + 8), b2 = *(const F2*)(g + 1608);
+                vrow[y0 + r] = fl[o] + fl[102400 + o] + a.a + a.d + q[4] + t0.a + t1.b + t2.a + b0.c + b1.d + b2.b;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (writer)
+#pragma unroll
+            for (int r = 0; r < SB; r++) {
+                const int y = yb + r;
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    D[pairbase + ((int64_t)(y >> 6) * 5 * kXch + c * kXch + (x >> 3)) * 512 + (y & 63) * 8 + ((x & 7) ^ (y & 7))] = vrow[r] + c;
+            }
+    }
+}
+
 template <typename F>
 static void timeit(const char* name, double bytes, F launch)
 {
@@ -198,6 +236,10 @@ int main()
                 printf("loads (4 rows in flight) and D stores as two concurrent kernels: %8.1f us  %6.2f TB/s\n", ms * 1e3, (rd + wr) / (ms * 1e-3) / 1e12);
             }
         }
+        timeit("2-row loads, D stores in bursts of 2 rows", rd + wr, [&] { uv_burst<2><<<nb, 256>>>(R, fl, b); });
+        timeit("2-row loads, D stores in bursts of 8 rows", rd + wr, [&] { uv_burst<8><<<nb, 256>>>(R, fl, b); });
+        timeit("2-row loads, D stores in bursts of 16 rows", rd + wr, [&] { uv_burst<16><<<nb, 256>>>(R, fl, b); });
+        timeit("2-row loads, D stores in bursts of 32 rows", rd + wr, [&] { uv_burst<32><<<nb, 256>>>(R, fl, b); });
         timeit("k_uv traffic, loads + D stores, 2 rows in flight", rd + wr, [&] { uv_traffic<2, true><<<nb, 256>>>(R, fl, b); });
         timeit("k_uv traffic, loads + D stores, 4 rows in flight", rd + wr, [&] { uv_traffic<4, true><<<nb, 256>>>(R, fl, b); });
         timeit("k_uv traffic, loads + D stores, 8 rows in flight", rd + wr, [&] { uv_traffic<8, true><<<nb, 256>>>(R, fl, b); });
