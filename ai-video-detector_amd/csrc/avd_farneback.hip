@@ -16,6 +16,7 @@
 //     read 10 consecutive floats), flow planar, D tiled + XOR-swizzled.
 // Not GEMM-shaped (11/19-tap separable stencils, 15x15 box sums, per-pixel 2x2 solves): HBM-traffic
 // bound by the exact re-enactment of cv2's running double sums; MFMA is not applicable.
+#include <cstdio>
 #include <cstdlib>
 #include "avd_internal.h"
 
@@ -249,16 +250,30 @@ struct NeG { float top[10], bot[10]; };            // (y1,x1..x1+1) and (y1+1,x1
 struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
 struct __attribute__((packed, aligned(4))) F2 { float a, b; };
 
-// R is interleaved [frame][y][x][5]; flow planar [pair][2][y][x].  Addressing is "uniform base +
-// 32-bit element offset" (R spans < 2^30 floats), wide loads on 4-byte-aligned addresses.
+// R is interleaved [frame][y][x][5]; flow planar [pair][2][y][x].  Addressing is "uniform base + unsigned
+// 32-bit BYTE offset" (both buffers are smaller than 4 GiB), which the compiler turns into the
+// saddr + voffset form of global_load: no 64-bit address arithmetic per load.  Wide loads on 4-byte-aligned
+// addresses.
+template <typename T>
+__device__ __forceinline__ T ld_off(const void* __restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+
+template <typename T>
+__device__ __forceinline__ void st_off(void* __restrict__ base, unsigned byte_off, T v)
+{
+    *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off) = v;
+}
+
 __device__ __forceinline__ void ne_load(const float* __restrict__ R, const float* __restrict__ flow, unsigned r0base,
                                         unsigned flbase, int x, int y, int w, int plane, NeIn& in)
 {
     const unsigned o = (unsigned)(y * w + x);
-    in.dx = flow[flbase + o]; in.dy = flow[flbase + plane + o];
-    const float* p = R + (r0base + o * 5u);
-    const F4 v = *reinterpret_cast<const F4*>(p);
-    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = p[4];
+    in.dx = ld_off<float>(flow, (flbase + o) * 4u); in.dy = ld_off<float>(flow, (flbase + plane + o) * 4u);
+    const unsigned pb = (r0base + o * 5u) * 4u;
+    const F4 v = ld_off<F4>(R, pb);
+    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off<float>(R, pb + 16u);
 }
 
 // gather the four bilinear neighbours of the warped position (clamped address when outside:
@@ -268,12 +283,11 @@ __device__ __forceinline__ void ne_gather(const float* __restrict__ R, unsigned 
 {
     const float fx = x + in.dx, fy = y + in.dy;
     const int x1 = clampi(floor_f(fx), 0, w - 2), y1 = clampi(floor_f(fy), 0, h - 2);
-    const float* p = R + (r1base + (unsigned)(y1 * w + x1) * 5u);
-    const float* q = p + w * 5;
-    const F4 t0 = *reinterpret_cast<const F4*>(p), t1 = *reinterpret_cast<const F4*>(p + 4);
-    const F2 t2 = *reinterpret_cast<const F2*>(p + 8);
-    const F4 b0 = *reinterpret_cast<const F4*>(q), b1 = *reinterpret_cast<const F4*>(q + 4);
-    const F2 b2 = *reinterpret_cast<const F2*>(q + 8);
+    const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
+    const F4 t0 = ld_off<F4>(R, pb), t1 = ld_off<F4>(R, pb + 16u);
+    const F2 t2 = ld_off<F2>(R, pb + 32u);
+    const F4 b0 = ld_off<F4>(R, qb), b1 = ld_off<F4>(R, qb + 16u);
+    const F2 b2 = ld_off<F2>(R, qb + 32u);
     g.top[0] = t0.a; g.top[1] = t0.b; g.top[2] = t0.c; g.top[3] = t0.d; g.top[4] = t1.a;
     g.top[5] = t1.b; g.top[6] = t1.c; g.top[7] = t1.d; g.top[8] = t2.a; g.top[9] = t2.b;
     g.bot[0] = b0.a; g.bot[1] = b0.b; g.bot[2] = b0.c; g.bot[3] = b0.d; g.bot[4] = b1.a;
@@ -334,25 +348,22 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
 // software-pipeline their own entries (stride NPROD rows): flow/R0 loads three phases ahead, gathers
 // one phase ahead, static register slots; their steps have no branches around memory operations.
 // ---------------------------------------------------------------------------------------
-#ifdef AVD_STAMPS
-#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-constexpr unsigned kStampOff = 127u * 5u * 320u * 8u;      // pair 127's VS0 region (unused below 128 pairs)
-#endif
 template <int W, int NPROD>
-__global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
+__global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
                                                            double* __restrict__ D16, double* __restrict__ VS0, int npairs)
 {
-    static_assert(NPROD == 3 || NPROD == 4, "ring size below covers 3 or 4 producers");
+    static_assert(NPROD >= 2 && NPROD <= 4 && 24 % NPROD == 0, "ring size below covers 2 to 4 producers");
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
-    constexpr int RSL = 24;                              // M-row ring in LDS: 15 rows of history + two phases of producer lead, multiple of NPROD
+    constexpr int RSL = 24;                              // M-row ring in LDS: 15 rows of history + two phases in flight (producers write phase k+1
+                                                         // while the summer still reads the leaving rows of phase k); 20 would collide
     constexpr int U = 4;                                 // phases per unrolled body (static producer register slots)
     constexpr int NE = H + m;                            // entries
     constexpr int NP = (NE + NPROD - 1) / NPROD;         // producing phases
-    constexpr int NPH = ((NP + 1 + U - 1) / U) * U;      // loop trip count (drain + round up to the unroll)
+    constexpr int NPH = ((NP + 2 + U - 1) / U) * U;      // loop trip count (two drain phases + round up to the unroll)
     __shared__ float ringM[RSL][5][64];                  // normal-equation rows, slot = entry % RSL (30 KiB)
-    __shared__ double Vb[NPROD][5][64];                  // the consumer's own exchange rows (wave-private)
+    __shared__ double Vb[2][NPROD][5][64];               // vsum rows of a phase, summer -> storer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // workgroups are dealt round-robin to the 8 XCDs; the strips of a pair share their halo columns and the
     // gathered R1 rows, so all strips of a pair go to one XCD (one L2): ~20 % fewer bytes fetched
@@ -363,28 +374,14 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
     if (wave == 0) {
-        // ------------------------------- consumer -------------------------------------------
-        // Stamped (s_memtime), this wave is the critical path of the workgroup, so a phase's NPROD rows are
-        // handled in passes: all LDS reads first, then the sequential double adds, then ONE exchange of
-        // the vsum rows (+7 / -8 lanes) and the stores.  Nothing but vs[] lives across phases.
-        const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
-        const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-        const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
-        const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
-        const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
+        // ------------------------------- summer ----------------------------------------------
+        // The only sequential part: five running double sums per column.  Phase k takes the rows the producers
+        // evaluated in phase k-1 (entries NPROD*(k-1) ..) and publishes the vsum rows.
         double vs[5] = {0, 0, 0, 0, 0};
-#ifdef AVD_STAMPS
-        unsigned long long cs0, cs1, cs2, csA = 0, csC = 0;
-#endif
-        for (int k = 0; k < NPH; k++) {                  // consumes the entries produced in phase k-1
-#ifdef AVD_STAMPS
-            STAMP(cs0);
-#endif
+        for (int k = 0; k < NPH; k++) {
             if (k >= 1 && k - 1 < NP) {
-                const int e0 = NPROD * (k - 1);
-                if (e0 + NPROD <= m) {
-                    // entries 0..m-1 only fill the box; nothing to do until the last of them is in
-                } else if (e0 < m) {
+                const int e0 = NPROD * (k - 1), pb = (k - 1) & 1;
+                if (e0 < m && e0 + NPROD >= m) {
                     // the phase that completes the initial box: vs = (m+2) * row 0 + rows 1..m-1, in that order
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
@@ -393,11 +390,13 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
                         for (int r = 1; r < m; r++) vs[c] += (double)ringM[r][c][lane];
                     }
                 }
+                // entering rows (this phase's entries) and the rows leaving the box with them (row y-8 = entry e-15;
+                // row 0 while the window still touches the top edge), all reads first
                 float a[NPROD][5], b[NPROD][5];
 #pragma unroll
                 for (int i = 0; i < NPROD; i++) {
                     const int e = e0 + i, y = e - m;
-                    const int sa = e % RSL, sb = y >= m + 1 ? (e - 15) % RSL : 0;     // row y-8 = entry e-15
+                    const int sa = e % RSL, sb = y >= m + 1 ? (e - 15) % RSL : 0;
 #pragma unroll
                     for (int c = 0; c < 5; c++) { a[i][c] = ringM[sa][c][lane]; b[i][c] = ringM[sb][c][lane]; }
                 }
@@ -408,16 +407,32 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
 #pragma unroll
                         for (int c = 0; c < 5; c++) {
                             vs[c] += (double)(a[i][c] - b[i][c]);
-                            Vb[i][c][lane] = vs[c];
+                            Vb[pb][i][c][lane] = vs[c];
                         }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    if (wave == 1) {
+        // ------------------------------- storer ----------------------------------------------
+        // Forms D = vsum(x+7) - vsum(x-8) of the rows the summer published a phase earlier and is the only
+        // wave that stores (D tiles, vsum columns 0..6): it never waits on memory.
+        const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
+        const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
+        const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+        const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+        const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
+        for (int k = 0; k < NPH; k++) {
+            if (k >= 2 && k - 2 < NP) {
+                const int e0 = NPROD * (k - 2), pb = (k - 2) & 1;
                 double dv[NPROD][5];
 #pragma unroll
                 for (int i = 0; i < NPROD; i++)
 #pragma unroll
-                    for (int c = 0; c < 5; c++) dv[i][c] = Vb[i][c][lhi] - Vb[i][c][llo];
+                    for (int c = 0; c < 5; c++) dv[i][c] = Vb[pb][i][c][lhi] - Vb[pb][i][c][llo];
 #pragma unroll
                 for (int i = 0; i < NPROD; i++) {
                     const int e = e0 + i, y = e - m;
@@ -426,50 +441,32 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
                             const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
                             const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
 #pragma unroll
-                            for (int c = 0; c < 5; c++) D16[t0 + (unsigned)c * XCH * 512u] = dv[i][c];
+                            for (int c = 0; c < 5; c++) st_off<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, dv[i][c]);
                         }
                         if (head) {
 #pragma unroll
-                            for (int c = 0; c < 5; c++) VS0[vbase + (unsigned)((c * H + y) * 8)] = Vb[i][c][lane];
+                            for (int c = 0; c < 5; c++) st_off<double>(VS0, (vbase + (unsigned)((c * H + y) * 8)) * 8u, Vb[pb][i][c][lane]);
                         }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
             }
-#ifdef AVD_STAMPS
-            STAMP(cs1);
-#endif
             __syncthreads();
-#ifdef AVD_STAMPS
-            STAMP(cs2); csA += cs1 - cs0; csC += cs2 - cs1;
-#endif
         }
-#ifdef AVD_STAMPS
-        if (W == 160 && blockIdx.x == 200 && lane == 0) { VS0[kStampOff + 0] = (double)csA; VS0[kStampOff + 1] = (double)csC; VS0[kStampOff + 2] = (double)NPH; }
-#endif
         return;
     }
 
     // ----------------------------------- producers ------------------------------------------
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
-    const int pi = wave - 1;                             // entry index inside a phase
+    const int pi = wave - 2;                             // entry index inside a phase
     NeIn in[4]; NeG g[2];
     auto row_of = [&](int k) { return min(NPROD * k + pi, H - 1); };
 #pragma unroll
     for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
     ne_gather(R, r1base, in[0], x, row_of(0), W, H, plane, g[0]);
-#ifdef AVD_STAMPS
-    unsigned long long ps0, ps1, ps2, ps3, ps4, psW = 0, psA = 0, psB = 0, psC = 0;
-#endif
     for (int kb = 0; kb < NPH; kb += U) {
 #pragma unroll
         for (int kk = 0; kk < U; kk++) {
             const int k = kb + kk;
-#ifdef AVD_STAMPS
-            STAMP(ps0);
-            __builtin_amdgcn_s_waitcnt(0x0F74);          // vmcnt(4): the six gather loads of the previous phase are back
-            STAMP(ps1);
-#endif
             if (k < NP) {
                 // rows past the last entry (e >= NE, only in the final phase) are evaluated on clamped
                 // addresses and never consumed: no branch around the loads
@@ -478,28 +475,13 @@ __global__ __launch_bounds__(64 * (NPROD + 1), 4) void k_uvp(const float* __rest
                 const int slot = (NPROD * k + pi) % RSL;
 #pragma unroll
                 for (int c = 0; c < 5; c++) ringM[slot][c][lane] = a[c];
-#ifdef AVD_STAMPS
-                STAMP(ps2);
-#endif
                 // refill: gathers of this wave's next entry, inputs three entries ahead
                 ne_gather(R, r1base, in[(kk + 1) & 3], x, row_of(k + 1), W, H, plane, g[(kk + 1) & 1]);
                 ne_load(R, flow, r0base, flbase, x, row_of(k + 3), W, plane, in[(kk + 3) & 3]);
             }
-#ifdef AVD_STAMPS
-            STAMP(ps3);
-#endif
             __syncthreads();
-#ifdef AVD_STAMPS
-            STAMP(ps4);
-            if (k < NP) { psW += ps1 - ps0; psA += ps2 - ps1; psB += ps3 - ps2; psC += ps4 - ps3; }
-#endif
         }
     }
-#ifdef AVD_STAMPS
-    if (W == 160 && blockIdx.x == 200 && lane == 0 && pi == 0) {
-        VS0[kStampOff + 8] = (double)psW; VS0[kStampOff + 9] = (double)psA; VS0[kStampOff + 10] = (double)psB; VS0[kStampOff + 11] = (double)psC;
-    }
-#endif
 }
 
 template <int W>
@@ -520,8 +502,7 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
     const int lane = threadIdx.x & 63;
     // all strips of a pair on one XCD (see k_uvp)
     const int sj = blockIdx.x >> 3;
-    const bool remap = !(npairs & 0x10000); npairs &= 0xffff;
-    const int p = remap ? (blockIdx.x & 7) + 8 * (sj / NSTRIP) : blockIdx.x / NSTRIP, strip = remap ? sj % NSTRIP : blockIdx.x % NSTRIP;
+    const int p = (blockIdx.x & 7) + 8 * (sj / NSTRIP), strip = sj % NSTRIP;
     if (p >= npairs) return;                             // both waves of a strip leave together
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
@@ -550,15 +531,15 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
                 const unsigned t1 = dbase + ((unsigned)(y1 >> 6) * 5 * XCH) * 512u + (y1 & 63) * 8 + sw1;
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    D16[t0 + (unsigned)c * XCH * 512u] = d0[c];
-                    D16[t1 + (unsigned)c * XCH * 512u] = d1[c];
+                    st_off<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, d0[c]);
+                    st_off<double>(D16, (t1 + (unsigned)c * XCH * 512u) * 8u, d1[c]);
                 }
             }
             if (head) {
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    VS0[vbase + (unsigned)((c * H + y0) * 8)] = h0[c];
-                    VS0[vbase + (unsigned)((c * H + y1) * 8)] = h1[c];
+                    st_off<double>(VS0, (vbase + (unsigned)((c * H + y0) * 8)) * 8u, h0[c]);
+                    st_off<double>(VS0, (vbase + (unsigned)((c * H + y1) * 8)) * 8u, h1[c]);
                 }
             }
         }
@@ -915,9 +896,9 @@ template <int W>
 void blur_iteration(const Seg& g, int k, int np)
 {
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    // AVD_UV_VARIANT: 0 = single-wave k_uv everywhere, 1 = producer/consumer k_uvp<4 producers> everywhere,
-    // 2 (default) = k_uvp<4> below full resolution (issue-bound levels), k_uv at 320x320 (bandwidth-bound),
-    // 3 = k_uvp<3 producers> everywhere, 4 = k_uvp<3> at 320x320 + k_uvp<4> below
+    // AVD_UV_VARIANT (A/B knob): 0 = k_uv everywhere, 1 / 3 / 5 = k_uvp with 4 / 3 / 2 producers everywhere,
+    // 2 (default) = k_uv at 320x320 (every design measured there lands at ~290-300 us: HBM read/write mix) and
+    // k_uvp<4> below (latency / issue bound levels), 4 / 6 = k_uvp<3> / k_uvp<2> at 320x320 + k_uvp<4> below
     static const int variant = [] { const char* e = std::getenv("AVD_UV_VARIANT"); return e ? std::atoi(e) : 2; }();
     // profiling: HIP events around the two full-resolution kernels (avd_stage_ms 4 and 5)
     auto mark = [&](void) {
@@ -925,17 +906,18 @@ void blur_iteration(const Seg& g, int k, int np)
     };
     mark();
     const int grid = 8 * ((np + 7) / 8) * NSTRIP;        // (XCD, pair-in-XCD, strip); pairs >= np exit at once
-    static const int noremap = [] { const char* e = std::getenv("AVD_NOREMAP"); return e ? std::atoi(e) : 0; }();
-    const int npx = np | (noremap ? 0x10000 : 0);
-    if (variant == 3 || (variant == 4 && W == S)) {
-        hipLaunchKernelGGL((k_uvp<W, 3>), dim3(grid), dim3(256), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, npx);
-    } else if (variant == 1 || ((variant == 2 || variant == 4) && W < S)) {
-        hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(320), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, npx);
+    if (variant == 5 || (variant == 6 && W == S)) {
+        hipLaunchKernelGGL((k_uvp<W, 2>), dim3(grid), dim3(256), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
+    } else if (variant == 3 || (variant == 4 && W == S)) {
+        hipLaunchKernelGGL((k_uvp<W, 3>), dim3(grid), dim3(320), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
+    } else if (variant == 1 || ((variant == 2 || variant == 4 || variant == 6) && W < S)) {
+        hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(384), 0, g.stream, (const float*)g.poly[k],
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
     } else {
         hipLaunchKernelGGL(k_uv<W>, dim3(grid), dim3(128), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, npx);
+                           (const float*)g.flow[k], g.vs, g.vs0, np);
     }
     mark(); mark();
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,
