@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) path, reported apart")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="clips in flight per GPU (each on its own avd context / stream / workspace): 1 = every step is "
+                         "submitted and drained alone (default, clean per-kernel timings); 2 = serving mode, the next "
+                         "clip's latency-bound coarse levels overlap the previous clip's bandwidth-bound level")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
@@ -140,33 +144,52 @@ def main():
     meta = {"width": w, "height": h, "fps": 30.0, "duration": n / 2.0}
     clip = synth.make_clip(n, h, w, seed=args.seed + rank)          # synthetic, SURVEY.md 8(d) recipe
     frames = torch.from_numpy(clip).to(dev)                          # resident in HBM before timing
-    ctx = avd_hip.Context(dev_index)
-    ctx.set_profiling(True)
-    rec = np.zeros(n, avd_hip.RECORD_DTYPE)
+    m = max(1, args.inflight)
+    ctxs = [avd_hip.Context(dev_index) for _ in range(m)]
+    for c in ctxs:
+        c.set_profiling(True)
+    ctx = ctxs[0]
+    recs = [np.zeros(n, avd_hip.RECORD_DTYPE) for _ in range(m)]
     hints = heuristics_v2.compute_hints({**meta, "bit_rate": 8_000_000}, "")
+    stage = np.zeros(6)
+    pending = []
 
-    def step():
-        ctx.analyze_frames_async(frames, rec)
-        ctx.synchronize()
+    def submit(i):
+        j = i % m
+        ctxs[j].analyze_frames_async(frames, recs[j])
+        pending.append(j)
+
+    def retire():
+        j = pending.pop(0)
+        ctxs[j].synchronize()
+        stage[:] += np.array(ctxs[j].stage_ms())
+        rec = recs[j]
         allrec = avd_dist.gather_fixed(rec, device=gather_dev) if use_dist else rec
         # scalar tail (video.py:54-83) + fusion (fusion.py:16) for this rank's clip; other clips' records are local too
         video = records_to_result(allrec[rank * n:(rank + 1) * n], h * w, w, h, meta["fps"], meta["duration"])
         fused = fusion.fuse(audio_unavailable("", meta), video, hints)
         return video, fused
 
+    def run(steps):
+        out = None
+        for i in range(steps):
+            if len(pending) == m:
+                out = retire()
+            submit(i)
+        while pending:
+            out = retire()
+        return out
+
     def barrier():
         if use_dist:
             tdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage = np.zeros(6)
+    run(args.warmup)
+    stage[:] = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result, fused = step()
-        stage += np.array(ctx.stage_ms())
+    result, fused = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -193,7 +216,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels; f32/f64 Farneback (cv2's own types)",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 1080p30 60 s clip, 2 fps sampling, one clip per GPU per step",
-                       "frames_per_clip": n, "height": h, "width": w, "clips_per_step": world,
+                       "frames_per_clip": n, "height": h, "width": w, "clips_per_step": world, "clips_in_flight_per_gpu": m,
                        "sec_per_video": round(ms_per_step / 1e3, 6),
                        "decoded_frame_equivalent_fps": round(fps_total * 15, 1),
                        "parallelism": f"clip-parallel x{world}, one all-gather ({args.backend}) of 32 B/frame records" if world > 1 else "single GPU"},
