@@ -227,3 +227,44 @@ def test_two_threads_two_contexts(ctx):
     assert ctxs[0] is not ctxs[1] and ctxs[0] is not ctx
     for i in range(2):
         assert np.array_equal(got[i], want[i])
+
+
+def test_full_size_clip_properties(ctx, oracle):
+    """BASELINE.json configs[1] at its full size (120 x 1080p, 119 pairs): too big for the oracle as a whole,
+    so parity is checked through properties that do not depend on the size -- locality (a frame's record only
+    depends on the frame and its predecessor), order reversal, exact duplicates, a constant frame -- plus
+    oracle spot checks of single frames and pairs."""
+    n, h, w = 120, 1080, 1920
+    clip = synth.make_clip(n, h, w, seed=0)                   # every 10th frame duplicates its predecessor
+    clip[77] = 93                                             # one constant frame
+    rec = ctx.analyze_frames(clip)
+    assert rec["ham"][0] == -1 and np.all(rec["ham"][1:] >= 0)
+    # exact duplicates: identical hash and moments; the flow is tiny but NOT zero (cv2 treats the last column
+    # and row as warped outside the image, so the normal equations there see a difference)
+    dups = [i for i in range(1, n) if np.array_equal(clip[i], clip[i - 1])]
+    assert len(dups) >= 10
+    for i in dups:
+        assert rec["ham"][i] == 0 and 0.0 <= rec["flow_mean"][i] < 1e-2 and rec["flow_var"][i] < 1e-2
+        assert rec["lap_sum"][i] == rec["lap_sum"][i - 1] and rec["lap_sumsq"][i] == rec["lap_sumsq"][i - 1]
+    # constant frame: the Laplacian vanishes identically
+    assert rec["lap_sum"][77] == 0 and rec["lap_sumsq"][77] == 0
+    # locality: a sub-clip reproduces the corresponding records bit for bit (except its own first frame's pair)
+    sub = ctx.analyze_frames(clip[40:61])
+    for key in ("lap_sum", "lap_sumsq"):
+        assert np.array_equal(sub[key], rec[key][40:61]), key
+    for key in ("flow_mean", "flow_var", "ham"):
+        assert np.array_equal(sub[key][1:], rec[key][41:61]), key
+    # order reversal: per-frame moments reverse, the Hamming distance of a pair is symmetric
+    rev = ctx.analyze_frames(clip[::-1])
+    assert np.array_equal(rev["lap_sum"], rec["lap_sum"][::-1])
+    assert np.array_equal(rev["lap_sumsq"], rec["lap_sumsq"][::-1])
+    assert np.array_equal(rev["ham"][1:], rec["ham"][1:][::-1])
+    # oracle spot checks: four single frames, two pairs (one across the scene cut in the middle)
+    for i in (0, 59, 60, 119):
+        small, hsh, s, q = oracle.preprocess_bgr(clip[i:i + 1])
+        assert rec["lap_sum"][i] == s[0] and rec["lap_sumsq"][i] == q[0]
+    for i in (33, 60, dups[0]):
+        small, hsh, s, q = oracle.preprocess_bgr(clip[i - 1:i + 1])
+        fm, fv = oracle.farneback_pairs(small)
+        assert rec["flow_mean"][i] == fm[0] and rec["flow_var"][i] == fv[0]
+        assert rec["ham"][i] == int(np.sum(hsh[0] ^ hsh[1]))
