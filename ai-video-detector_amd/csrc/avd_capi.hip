@@ -61,6 +61,7 @@ void free_ws(Workspace& ws)
     F(ws.d_tables);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
+    if (ws.h_rec) (void)hipHostFree(ws.h_rec);
     ws = Workspace{};
 }
 
@@ -144,6 +145,10 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
         if (int e = dev_alloc(ctx, ws.d_lap, (size_t)cap * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_lap_part, (size_t)cap * ws.pre.nbands * 8 * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_rec, (size_t)cap)) return e;
+        if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
+        if (hipHostMalloc((void**)&ws.h_rec, sizeof(avd_frame_record) * cap, hipHostMallocDefault) != hipSuccess) {
+            ctx->err = "hipHostMalloc failed"; return AVD_ERR_NOMEM;
+        }
         ws.cap_n = cap; ws.h = h; ws.w = w;
     }
     return 0;
@@ -380,6 +385,7 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
     if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
     if (n == 0) return AVD_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending_out) { if (int e = avd_synchronize(ctx)) return e; }     // a previous call was never drained
     if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
     if (int e = avd_ws_reserve_fb(ctx, n)) return e;
     const uint8_t* d_bgr = nullptr;
@@ -396,7 +402,10 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
     stage_mark(ctx, 2);
     if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true)) return e;
     stage_mark(ctx, 3);
-    HIP_TRY(ctx, hipMemcpyAsync(records, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
+    // into PINNED memory: a device-to-host copy into the caller's pageable buffer would block this thread until
+    // the whole clip is done and the call would not be asynchronous at all; avd_synchronize hands the records over
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending_out = records; ctx->pending_n = n;
     stage_mark(ctx, 4);
     ctx->last_n = n;
     return AVD_OK;
@@ -406,6 +415,10 @@ int avd_synchronize(avd_ctx* ctx)
 {
     if (!ctx) return AVD_ERR_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pending_out) {
+        std::memcpy(ctx->pending_out, ctx->ws.h_rec, sizeof(avd_frame_record) * ctx->pending_n);
+        ctx->pending_out = nullptr; ctx->pending_n = 0;
+    }
     if (ctx->profiling) {
         // stages: 0 preprocess, 1 hash+hamming+records, 2 farneback+stats (3 reported as copy-out)
         for (int i = 0; i < 4; i++) {

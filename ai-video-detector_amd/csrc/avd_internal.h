@@ -98,6 +98,7 @@ struct Workspace {
     float* d_stats = nullptr;             // [n-1][2] mean, var
     float* d_part = nullptr;              // [n-1][2][13] per-buffer partial sums (numpy reduction order)
     avd_frame_record* d_rec = nullptr;    // [n]
+    avd_frame_record* h_rec = nullptr;    // [n] pinned landing buffer of the asynchronous copy-out
 };
 
 struct avd_ctx {
@@ -107,6 +108,8 @@ struct avd_ctx {
     hipStream_t stream2 = nullptr;      // second Farneback segment of a clip runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    avd_frame_record* pending_out = nullptr;   // caller buffer the pinned records are handed to in avd_synchronize
+    int pending_n = 0;
     hipEvent_t stage_ev[5] = {};
     hipEvent_t kern_ev[12] = {};           // profiling: start/stop of the 3 k_uv<320> and 3 k_hscan<320> launches of a segment
     int kern_ev_used = 0;

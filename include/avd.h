@@ -93,9 +93,13 @@ int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, 
                        int64_t row_stride, int64_t frame_stride,
                        avd_frame_record* records);
 
-/* Same, but only enqueues the work on ctx's stream and returns; records (HOST
- * memory, ideally pinned) are valid after avd_synchronize.  Used by bench.py to
- * time kernels with HIP events on the stream they run on. */
+/* Same, but only enqueues the work on ctx's stream and returns; records (any HOST
+ * memory) are filled by avd_synchronize: the device-to-host copy lands in a pinned
+ * buffer of the library, so the call never blocks on it and several contexts can
+ * keep clips in flight on one GPU.  One call may be outstanding per context (a
+ * second one drains the first).  With AVD_MEM_HOST input the frames are staged by
+ * hipMemcpyAsync from the caller's buffer, which is only asynchronous if that buffer
+ * is pinned. */
 int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
                              int64_t row_stride, int64_t frame_stride,
                              avd_frame_record* records);
