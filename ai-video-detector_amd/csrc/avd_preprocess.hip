@@ -40,26 +40,32 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 // 15-bit fixed-point luma, split into byte coefficients for v_dot4_u32_u8:
 //   3735 = 14*256+151 (B)   19235 = 75*256+35 (G)   9798 = 38*256+70 (R)
-constexpr unsigned kHi = 14u | (75u << 8) | (38u << 16);
+// gray = (256 h + l) >> 15 with h = px . hi, l = px . lo + 2^14.  Since 256 h + l = 256 (h + (l >> 8)) + (l & 255),
+// gray = (h + (l >> 8)) >> 7 = byte 1 of 2 h + 2 (l >> 8); 2 (l >> 8) and l >> 7 differ in bit 0 only and 2 h is even,
+// so byte 1 of  v = px . (2 hi) + (l >> 7)  is the gray value: dot4, shift, dot4 -- and the four results of a
+// quad are packed by two v_perm picking byte 1 of each.
+constexpr unsigned kHi2 = 28u | (150u << 8) | (76u << 16);
 constexpr unsigned kLo = 151u | (35u << 8) | (70u << 16);
 
-__device__ __forceinline__ unsigned gray_of(unsigned px, unsigned hi, unsigned lo)
+__device__ __forceinline__ unsigned gray_v(unsigned px, unsigned hi2, unsigned lo)
 {
-    unsigned h = __builtin_amdgcn_udot4(px, hi, 0u, false);
-    unsigned l = __builtin_amdgcn_udot4(px, lo, 1u << 14, false);
-    return ((h << 8) + l) >> 15;
+    const unsigned l = __builtin_amdgcn_udot4(px, lo, 1u << 14, false);
+    return __builtin_amdgcn_udot4(px, hi2, l >> 7, false);       // gray in bits 8..15
 }
 
 // 12 bytes (4 BGR pixels) -> 4 gray bytes packed little-endian
 __device__ __forceinline__ unsigned gray4(unsigned w0, unsigned w1, unsigned w2)
 {
-    unsigned p1 = __builtin_amdgcn_alignbyte(w1, w0, 3);
-    unsigned p2 = __builtin_amdgcn_alignbyte(w2, w1, 2);
-    unsigned g0 = gray_of(w0, kHi, kLo);
-    unsigned g1 = gray_of(p1, kHi, kLo);
-    unsigned g2 = gray_of(p2, kHi, kLo);
-    unsigned g3 = gray_of(w2, kHi << 8, kLo << 8);
-    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    const unsigned p1 = __builtin_amdgcn_alignbyte(w1, w0, 3);
+    const unsigned p2 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+    const unsigned v0 = gray_v(w0, kHi2, kLo);
+    const unsigned v1 = gray_v(p1, kHi2, kLo);
+    const unsigned v2 = gray_v(p2, kHi2, kLo);
+    const unsigned v3 = gray_v(w2, kHi2 << 8, kLo << 8);
+    // v_perm_b32(hi, lo, sel): byte k of the result = byte sel[k] of {hi:lo} (0..3 = lo, 4..7 = hi)
+    const unsigned g01 = __builtin_amdgcn_perm(v1, v0, 0x0c0c0501u);     // [v0.b1, v1.b1, 0, 0]
+    const unsigned g23 = __builtin_amdgcn_perm(v3, v2, 0x05010c0cu);     // [0, 0, v2.b1, v3.b1]
+    return g01 | g23;
 }
 
 __device__ __forceinline__ unsigned gray1(const uint8_t* p)
@@ -154,25 +160,52 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
         const int quads = (w + 3) >> 2;
         const int trows = rows + 2;
         const unsigned ones = 0x01010101u;
-        unsigned iA = 0, iHR = 0, iH2 = 0, iV1 = 0, iV2 = 0, iDp = 0, iDm = 0;   // interior rows
-        int bq = 0, bs = 0;                                                        // boundary rows, weighted
+        unsigned iA = 0, iHR = 0, iH2 = 0, iV1 = 0, iV2 = 0, iDp = 0, iDm = 0;   // products with the interior weights
+        int xA = 0;                                                                // A with weight 1 (signed: also corrects 20 -> 19)
+        unsigned xV1 = 0, xD = 0;                                                  // V1 with weight -8, Dp + Dm with weight 2
+        int bq = 0, bs = 0;                                                        // generic path (rows < 2) and row sums
+        const bool ragged = (w & 3) != 0;
         for (int qx = tid; qx < quads; qx += kThreads) {
             const uint8_t* col = tile + kPad + qx * 4;
             unsigned mk = 0xFFFFFFFFu;
-            if (w & 3) {                                   // ragged last quad: drop pixels >= w
+            if (ragged) {                                  // ragged last quad: drop pixels >= w
                 const int valid = w - qx * 4;
                 if (valid < 4) mk = (1u << (8 * valid)) - 1u;
             }
-            unsigned C1 = 0, C2 = 0;                       // rows n-1, n-2
-            for (int nrow = 0; nrow < trows; nrow++) {
+            auto ld = [&](int nrow, unsigned& C, unsigned& L, unsigned& R) {
                 const uint8_t* cp = col + nrow * pitch;
                 const unsigned Cw = *reinterpret_cast<const unsigned*>(cp);
                 const unsigned Lw = *reinterpret_cast<const unsigned*>(cp - 4);
                 const unsigned Rw = *reinterpret_cast<const unsigned*>(cp + 4);
-                const unsigned C = Cw & mk;
-                const unsigned L = __builtin_amdgcn_alignbyte(Cw, Lw, 3) & mk;
-                const unsigned R = __builtin_amdgcn_alignbyte(Rw, Cw, 1) & mk;
-                if (nrow >= 2 && nrow <= rows - 1) {
+                C = Cw; L = __builtin_amdgcn_alignbyte(Cw, Lw, 3); R = __builtin_amdgcn_alignbyte(Rw, Cw, 1);
+                if (ragged) { C &= mk; L &= mk; R &= mk; }
+            };
+            unsigned C, L, R, C1, C2;
+            if (rows >= 2) {
+                // The four boundary rows are peeled (their weights differ from the interior ones only in a few
+                // places, which go to the x* accumulators), so the interior loop is seven dot4 and no branch:
+                //   row 0      : A x1, row sum +1
+                //   row 1      : as interior but A x19, V1 x-8, no V2, Dp/Dm x2, row sum -1
+                //   row rows   : as interior but A x19, row sum -1
+                //   row rows+1 : A x1, V1 x-8, V2 x2, Dp/Dm x2, row sum +1
+                ld(0, C, L, R);
+                xA += (int)__builtin_amdgcn_udot4(C, C, 0u, false);
+                bs += (int)__builtin_amdgcn_udot4(C, ones, 0u, false);
+                C1 = C;
+                ld(1, C, L, R);
+                {
+                    const unsigned t = __builtin_amdgcn_udot4(C, C, 0u, false);
+                    iA += t; xA -= (int)t;
+                    iHR = __builtin_amdgcn_udot4(C, R, iHR, false);
+                    iH2 = __builtin_amdgcn_udot4(L, R, iH2, false);
+                    xV1 = __builtin_amdgcn_udot4(C1, C, xV1, false);
+                    xD = __builtin_amdgcn_udot4(C1, R, xD, false);
+                    xD = __builtin_amdgcn_udot4(C1, L, xD, false);
+                    bs -= (int)__builtin_amdgcn_udot4(C, ones, 0u, false);
+                }
+                C2 = C1; C1 = C;
+                for (int nrow = 2; nrow <= rows - 1; nrow++) {
+                    ld(nrow, C, L, R);
                     iA = __builtin_amdgcn_udot4(C, C, iA, false);
                     iHR = __builtin_amdgcn_udot4(C, R, iHR, false);
                     iH2 = __builtin_amdgcn_udot4(L, R, iH2, false);
@@ -180,7 +213,33 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
                     iV2 = __builtin_amdgcn_udot4(C2, C, iV2, false);
                     iDp = __builtin_amdgcn_udot4(C1, R, iDp, false);
                     iDm = __builtin_amdgcn_udot4(C1, L, iDm, false);
-                } else {
+                    C2 = C1; C1 = C;
+                }
+                ld(rows, C, L, R);
+                {
+                    const unsigned t = __builtin_amdgcn_udot4(C, C, 0u, false);
+                    iA += t; xA -= (int)t;
+                    iHR = __builtin_amdgcn_udot4(C, R, iHR, false);
+                    iH2 = __builtin_amdgcn_udot4(L, R, iH2, false);
+                    iV1 = __builtin_amdgcn_udot4(C1, C, iV1, false);
+                    iV2 = __builtin_amdgcn_udot4(C2, C, iV2, false);
+                    iDp = __builtin_amdgcn_udot4(C1, R, iDp, false);
+                    iDm = __builtin_amdgcn_udot4(C1, L, iDm, false);
+                    bs -= (int)__builtin_amdgcn_udot4(C, ones, 0u, false);
+                }
+                C2 = C1; C1 = C;
+                ld(rows + 1, C, L, R);
+                xA += (int)__builtin_amdgcn_udot4(C, C, 0u, false);
+                xV1 = __builtin_amdgcn_udot4(C1, C, xV1, false);
+                iV2 = __builtin_amdgcn_udot4(C2, C, iV2, false);
+                xD = __builtin_amdgcn_udot4(C1, R, xD, false);
+                xD = __builtin_amdgcn_udot4(C1, L, xD, false);
+                bs += (int)__builtin_amdgcn_udot4(C, ones, 0u, false);
+            } else {
+                // a one-row band (last band of some geometries): every tile row is a boundary row
+                C1 = 0; C2 = 0;
+                for (int nrow = 0; nrow < trows; nrow++) {
+                    ld(nrow, C, L, R);
                     const int in0 = nrow >= 1 && nrow <= rows;          // n   in B
                     const int inm = nrow >= 2 && nrow <= rows + 1;      // n-1 in B
                     const int inp = nrow + 1 <= rows;                   // n+1 in B  (n >= 0 always)
@@ -193,11 +252,12 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
                     bq += 2 * wP * (int)__builtin_amdgcn_udot4(C1, R, 0u, false);
                     bq += 2 * wP * (int)__builtin_amdgcn_udot4(C1, L, 0u, false);
                     bs += (inp + inm - 2 * in0) * (int)__builtin_amdgcn_udot4(C, ones, 0u, false);
+                    C2 = C1; C1 = C;
                 }
-                C2 = C1; C1 = C;
             }
         }
-        q_acc = 20ll * iA - 16ll * iHR + 2ll * iH2 - 16ll * iV1 + 2ll * iV2 + 4ll * iDp + 4ll * iDm + bq;
+        q_acc = 20ll * iA - 16ll * iHR + 2ll * iH2 - 16ll * iV1 + 2ll * iV2 + 4ll * iDp + 4ll * iDm
+                + (long long)xA - 8ll * xV1 + 2ll * xD + bq;
         s_acc = bs;
         // edge terms of band row t (tile row t = tid + 1): the l/r shifted sums run over x-1 / x+1
         if (tid < rows) {
