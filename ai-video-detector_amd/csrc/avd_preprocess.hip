@@ -23,6 +23,7 @@
 // dependent float chains of INTER_AREA want thread-level parallelism more than prefetch.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "avd_internal.h"
 
 namespace {
@@ -164,7 +165,9 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
         int xA = 0;                                                                // A with weight 1 (signed: also corrects 20 -> 19)
         unsigned xV1 = 0, xD = 0;                                                  // V1 with weight -8, Dp + Dm with weight 2
         int bq = 0, bs = 0;                                                        // generic path (rows < 2) and row sums
-        const bool ragged = (w & 3) != 0;
+        // two compiled versions: only widths that are not a multiple of 4 need the mask of the last quad
+        auto walk = [&](auto ragged_tag) {
+        constexpr bool ragged = decltype(ragged_tag)::value;
         for (int qx = tid; qx < quads; qx += kThreads) {
             const uint8_t* col = tile + kPad + qx * 4;
             unsigned mk = 0xFFFFFFFFu;
@@ -256,6 +259,8 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
                 }
             }
         }
+        };
+        if (w & 3) walk(std::true_type{}); else walk(std::false_type{});
         q_acc = 20ll * iA - 16ll * iHR + 2ll * iH2 - 16ll * iV1 + 2ll * iV2 + 4ll * iDp + 4ll * iDm
                 + (long long)xA - 8ll * xV1 + 2ll * xD + bq;
         s_acc = bs;
@@ -329,15 +334,22 @@ __device__ __forceinline__ Moments band_phases(const uint8_t* tile, const LdsTab
     if (!(P.dbg_skip & 4)) {
         const int d0 = P.band_dy[band], d1 = P.band_dy[band + 1];        // wave-uniform scalar loads
         uint8_t* dst = small + (int64_t)f * AVD_NPIX;
-        for (int it = tid; it < (d1 - d0) * AVD_SMALL; it += kThreads) {
-            const int dyi = it / AVD_SMALL, dx = it - dyi * AVD_SMALL, dy = d0 + dyi;
+        // a lane owns output COLUMNS (its x taps are unpacked once); the rows of the band are walked with
+        // wave-uniform y taps held in scalar registers
+        for (int dx = tid; dx < AVD_SMALL; dx += kThreads) {
             const LinTap tx = LTAB ? lt->lxt[dx] : P.lxt[dx];
-            const LinTap ty = LTAB ? lt->lyt[dy] : P.lyt[dy];
-            const uint8_t* ra = tile + (ty.i0 - r0 + 1) * pitch + kPad;
-            const uint8_t* rb = tile + (ty.i1 - r0 + 1) * pitch + kPad;
-            const int ha = ra[tx.i0] * tx.w0 + ra[tx.i1] * tx.w1;
-            const int hb = rb[tx.i0] * tx.w0 + rb[tx.i1] * tx.w1;
-            dst[dy * AVD_SMALL + dx] = (uint8_t)((((ty.w0 * (ha >> 4)) >> 16) + ((ty.w1 * (hb >> 4)) >> 16) + 2) >> 2);
+            const int x0 = tx.i0, x1 = tx.i1, wx0 = tx.w0, wx1 = tx.w1;
+            for (int dy = d0; dy < d1; dy++) {
+                const uint2 tyw = *reinterpret_cast<const uint2*>(LTAB ? &lt->lyt[dy] : &P.lyt[dy]);
+                const unsigned ta = __builtin_amdgcn_readfirstlane(tyw.x), tb = __builtin_amdgcn_readfirstlane(tyw.y);
+                const int yi0 = (short)(ta & 0xffffu), yi1 = (short)(ta >> 16);
+                const int wy0 = (short)(tb & 0xffffu), wy1 = (short)(tb >> 16);
+                const uint8_t* ra = tile + (yi0 - r0 + 1) * pitch + kPad;
+                const uint8_t* rb = tile + (yi1 - r0 + 1) * pitch + kPad;
+                const int ha = ra[x0] * wx0 + ra[x1] * wx1;
+                const int hb = rb[x0] * wx0 + rb[x1] * wx1;
+                dst[dy * AVD_SMALL + dx] = (uint8_t)((((wy0 * (ha >> 4)) >> 16) + ((wy1 * (hb >> 4)) >> 16) + 2) >> 2);
+            }
         }
     }
     Moments m;
