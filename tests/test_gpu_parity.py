@@ -268,3 +268,19 @@ def test_full_size_clip_properties(ctx, oracle):
         fm, fv = oracle.farneback_pairs(small)
         assert rec["flow_mean"][i] == fm[0] and rec["flow_var"][i] == fv[0]
         assert rec["ham"][i] == int(np.sum(hsh[0] ^ hsh[1]))
+
+
+def test_clips_in_flight_equal_one_at_a_time(ctx):
+    """Service throughput mode: several clips in flight on their own contexts return, in submission order, exactly
+    the records of one-at-a-time analysis (different geometries and lengths, more clips than contexts)."""
+    import avd_hip
+    clips = [(f"clip{i}", synth.make_clip(n, h, w, seed=50 + i, dup_every=3))
+             for i, (n, h, w) in enumerate([(7, 360, 640), (3, 240, 426), (12, 720, 1280), (2, 67, 101), (9, 360, 640),
+                                            (5, 1080, 1920), (4, 96, 128)])]
+    runner = avd_hip.ClipsInFlight(device=0, depth=3)
+    got = list(runner.run(clips))
+    assert [t for t, _ in got] == [t for t, _ in clips]
+    for (tag, rec), (_, frames) in zip(got, clips):
+        want = ctx.analyze_frames(frames)
+        for key in ("lap_sum", "lap_sumsq", "flow_mean", "flow_var", "ham"):
+            assert np.array_equal(rec[key], want[key]), (tag, key)
