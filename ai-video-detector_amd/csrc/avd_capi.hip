@@ -206,33 +206,13 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
     float* saved_il = ws.d_flow_il;
     if (!h_flow_out) ws.d_flow_il = nullptr;
     int rc = 0;
-    // Measured (round 1): splitting a 119-pair clip over two streams does not help (3.08 vs 3.02 ms) -- the level-0
-    // kernels are HBM-bound and simply share the bandwidth -- so one stream is the default; AVD_FB_STREAMS=2 enables it.
-    static const bool two_streams = [] { const char* e = std::getenv("AVD_FB_STREAMS"); return e && std::atoi(e) == 2; }();
     for (int p0 = 0; p0 < n - 1 && rc == 0; p0 += kFbChunk) {
         const int np = std::min(kFbChunk, n - 1 - p0);
-        // pairs [0, n1) of the chunk on the main stream, pairs [n1, np) on the second stream: independent work
-        // (flow is never warm-started); the second segment stores its frames one slot further so the slices are disjoint
-        const int n1 = (two_streams && np >= 16) ? np / 2 : np;
         const uint8_t* base = d_small + (size_t)p0 * AVD_NPIX;
-        if (n1 < np) {
-            hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = AVD_ERR_DEVICE; break; }
-            rc = launch_farneback(ctx, ctx->stream2, base + (size_t)n1 * AVD_NPIX, np - n1 + 1, n1 + 1, n1);
-            if (rc) break;
-            rc = launch_flow_stats(ctx, ctx->stream2, np - n1 + 1, n1 + 1, n1);
-            if (rc) break;
-        }
-        rc = launch_farneback(ctx, ctx->stream, base, n1 + 1, 0, 0);
+        rc = launch_farneback(ctx, ctx->stream, base, np + 1, 0, 0);
         if (rc) break;
-        rc = launch_flow_stats(ctx, ctx->stream, n1 + 1, 0, 0);
+        rc = launch_flow_stats(ctx, ctx->stream, np + 1, 0, 0);
         if (rc) break;
-        if (n1 < np) {
-            hipError_t e = hipEventRecord(ctx->ev_join, ctx->stream2);
-            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = AVD_ERR_DEVICE; break; }
-        }
         if (into_records) {
             hipLaunchKernelGGL(k_records, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
                                (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats,
@@ -293,9 +273,6 @@ int avd_create(int device_id, avd_ctx** out)
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
     for (int i = 0; ok && i < 12; i++) ok = hipEventCreate(&ctx->kern_ev[i]) == hipSuccess;
@@ -317,16 +294,12 @@ void avd_destroy(avd_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     free_ws(ctx->ws);
     if (ctx->d_fbc) (void)hipFree(ctx->d_fbc);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kern_ev) if (e) (void)hipEventDestroy(e);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

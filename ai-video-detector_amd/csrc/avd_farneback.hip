@@ -841,8 +841,9 @@ __global__ void k_flow_interleave(const float* __restrict__ flow, float* __restr
 }
 
 // A segment = a run of consecutive pairs processed on one stream, with its own slice of the workspace
-// (frames [frame_off, ...) and pairs [pair_off, ...) of the chunk), so that two segments of a clip can
-// be in flight on two streams: the small-level launches of one fill the latency gaps of the other.
+// (frames [frame_off, ...) and pairs [pair_off, ...) of the chunk).  The library runs one segment per chunk:
+// splitting a clip over two streams did not pay (the level-0 kernels share the bandwidth, the latency-bound
+// levels are duplicated); keeping several CLIPS in flight on separate contexts is what fills the gaps.
 struct Seg {
     hipStream_t stream;
     const float* pyr[AVD_FB_LEVELS];
@@ -896,9 +897,9 @@ template <int W>
 void blur_iteration(const Seg& g, int k, int np)
 {
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    // AVD_UV_VARIANT (A/B knob): 0 = k_uv everywhere, 1 / 3 / 5 = k_uvp with 4 / 3 / 2 producers everywhere,
-    // 2 (default) = k_uv at 320x320 (every design measured there lands at ~290-300 us: HBM read/write mix) and
-    // k_uvp<4> below (latency / issue bound levels), 4 / 6 = k_uvp<3> / k_uvp<2> at 320x320 + k_uvp<4> below
+    // AVD_UV_VARIANT (A/B knob): 0 = k_uv everywhere, 1 = k_uvp (4 producers) everywhere, 2 (default) = k_uv at
+    // 320x320 (every design measured there lands at ~290-300 us: HBM read/write mix; k_uvp with 2 / 3 / 4 producers
+    // 293 / 377 / 340 us) and k_uvp below (latency / issue bound levels)
     static const int variant = [] { const char* e = std::getenv("AVD_UV_VARIANT"); return e ? std::atoi(e) : 2; }();
     // profiling: HIP events around the two full-resolution kernels (avd_stage_ms 4 and 5)
     auto mark = [&](void) {
@@ -906,13 +907,7 @@ void blur_iteration(const Seg& g, int k, int np)
     };
     mark();
     const int grid = 8 * ((np + 7) / 8) * NSTRIP;        // (XCD, pair-in-XCD, strip); pairs >= np exit at once
-    if (variant == 5 || (variant == 6 && W == S)) {
-        hipLaunchKernelGGL((k_uvp<W, 2>), dim3(grid), dim3(256), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
-    } else if (variant == 3 || (variant == 4 && W == S)) {
-        hipLaunchKernelGGL((k_uvp<W, 3>), dim3(grid), dim3(320), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
-    } else if (variant == 1 || ((variant == 2 || variant == 4 || variant == 6) && W < S)) {
+    if (variant == 1 || (variant == 2 && W < S)) {
         hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(384), 0, g.stream, (const float*)g.poly[k],
                            (const float*)g.flow[k], g.vs, g.vs0, np);
     } else {

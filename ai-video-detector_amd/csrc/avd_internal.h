@@ -105,8 +105,6 @@ struct avd_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // second Farneback segment of a clip runs here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     avd_frame_record* pending_out = nullptr;   // caller buffer the pinned records are handed to in avd_synchronize
     int pending_n = 0;
