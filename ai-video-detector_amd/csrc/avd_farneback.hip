@@ -365,11 +365,12 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
     __shared__ float ringM[RSL][5][64];                  // normal-equation rows, slot = entry % RSL (30 KiB)
     __shared__ double Vb[2][NPROD][5][64];               // vsum rows of a phase, summer -> storer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // workgroups are dealt round-robin to the 8 XCDs; the strips of a pair share their halo columns and the
-    // gathered R1 rows, so all strips of a pair go to one XCD (one L2): ~20 % fewer bytes fetched
-    const int sj = blockIdx.x >> 3;
-    const int p = (blockIdx.x & 7) + 8 * (sj / NSTRIP), strip = sj % NSTRIP;
-    if (p >= npairs) return;
+    // workgroups are dealt round-robin to the 8 XCDs.  The strips of a pair share their halo columns and the
+    // gathered R1 rows, and pair p+1 reads as R0 the frame that pair p gathers as R1, at about the same rows at
+    // about the same time: so an XCD (one L2) gets all strips of a CONTIGUOUS run of pairs.
+    const int sj = blockIdx.x >> 3, ppx = (npairs + 7) >> 3;
+    const int p = (blockIdx.x & 7) * ppx + sj / NSTRIP, strip = sj % NSTRIP;
+    if (sj / NSTRIP >= ppx || p >= npairs) return;
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
@@ -500,10 +501,10 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
     __shared__ float ringl[16][5][64];                  // the compute wave's last 16 evaluated rows, slot = row & 15
     const int wv = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    // all strips of a pair on one XCD (see k_uvp)
-    const int sj = blockIdx.x >> 3;
-    const int p = (blockIdx.x & 7) + 8 * (sj / NSTRIP), strip = sj % NSTRIP;
-    if (p >= npairs) return;                             // both waves of a strip leave together
+    // all strips of a contiguous run of pairs on one XCD (see k_uvp)
+    const int sj = blockIdx.x >> 3, ppx = (npairs + 7) >> 3;
+    const int p = (blockIdx.x & 7) * ppx + sj / NSTRIP, strip = sj % NSTRIP;
+    if (sj / NSTRIP >= ppx || p >= npairs) return;       // both waves of a strip leave together
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
