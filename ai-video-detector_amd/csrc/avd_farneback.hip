@@ -110,11 +110,15 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ sma
 // float into LDS (3 moment planes, replicate border), horizontal pass with double
 // accumulators, output 5 interleaved coefficients R[y][x][c].
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, int w, int h,
+__global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, int w, int h, int total,
                                                 const FbConsts* __restrict__ C, float* __restrict__ R)
 {
     __shared__ float row[3][S + 10];
-    const int y = blockIdx.x % h, f = blockIdx.x / h;
+    // consecutive rows read overlapping 11-row windows: give an XCD (one L2) a contiguous run of rows
+    // (the grid is padded to a multiple of 8; total = frames x rows)
+    const int per = gridDim.x >> 3, lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lid >= total) return;
+    const int y = lid % h, f = lid / h;
     const int x = threadIdx.x;
     const float* img = I + (int64_t)f * w * h;
     const float* g = C->g + 5; const float* xg = C->xg + 5; const float* xxg = C->xxg + 5;
@@ -890,7 +894,7 @@ void pyramid_level(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int n)
     constexpr int WL = S >> K;
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
     hipLaunchKernelGGL(k_pyramid<K>, dim3(n * (WL / 8)), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[K]);
-    hipLaunchKernelGGL(k_polyexp, dim3(n * WL), dim3(320), 0, g.stream, g.pyr[K], WL, WL, C, g.poly[K]);
+    hipLaunchKernelGGL(k_polyexp, dim3(8 * ((n * WL + 7) / 8)), dim3(320), 0, g.stream, g.pyr[K], WL, WL, n * WL, C, g.poly[K]);
 }
 
 // one FarnebackUpdateFlow_Blur iteration at level k: matrices from the current flow, box sums, solve
