@@ -18,7 +18,9 @@ for i in range(cases):
     h = int(rng.integers(32, 600)); w = int(rng.integers(32, 900))
     if rng.random() < 0.4:
         w = (w // 16 + 1) * 16                      # aligned fast path
-    n = int(rng.integers(1, 7))
+    n = int(rng.integers(1, 7)) if rng.random() < 0.7 else int(rng.integers(8, 42))     # some longer clips: pair counts around the XCD run length
+    if n > 7:
+        h, w = min(h, 160), min(w, 208)
     kind = rng.integers(0, 3)
     if kind == 0:
         clip = synth.random_frames(n, h, w, seed=int(rng.integers(1 << 30)))
