@@ -902,9 +902,10 @@ template <int W>
 void blur_iteration(const Seg& g, int k, int np)
 {
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
-    // AVD_UV_VARIANT (A/B knob): 0 = k_uv everywhere, 1 = k_uvp (4 producers) everywhere, 2 (default) = k_uv at
-    // 320x320 (every design measured there lands at ~290-300 us: HBM read/write mix; k_uvp with 2 / 3 / 4 producers
-    // 293 / 377 / 340 us) and k_uvp below (latency / issue bound levels)
+    // AVD_UV_VARIANT (A/B knob): 0 = k_uv everywhere, 1 = k_uvp (4 producers) everywhere, 2 (default) = k_uvp
+    // below 320x320 (latency / issue bound levels) and, at 320x320, k_uv for long clips (every design measured there
+    // with 119 pairs lands at ~290-300 us: HBM read/write mix; k_uvp with 2 / 3 / 4 producers 293 / 377 / 340 us)
+    // and k_uvp for clips short enough to be resident in one round
     static const int variant = [] { const char* e = std::getenv("AVD_UV_VARIANT"); return e ? std::atoi(e) : 2; }();
     // profiling: HIP events around the two full-resolution kernels (avd_stage_ms 4 and 5)
     auto mark = [&](void) {
@@ -912,7 +913,10 @@ void blur_iteration(const Seg& g, int k, int np)
     };
     mark();
     const int grid = 8 * ((np + 7) / 8) * NSTRIP;        // (XCD, pair-in-XCD, strip); pairs >= np exit at once
-    if (variant == 1 || (variant == 2 && W < S)) {
+    // at 320x320 the producer / consumer form wins as long as all its workgroups are resident at once (3 per CU,
+    // 50 KiB of LDS each): ~170 us per launch instead of ~290 us; beyond that it needs a second residency round
+    const bool uvp_fits = np * NSTRIP <= 3 * 256;
+    if (variant == 1 || (variant == 2 && (W < S || uvp_fits))) {
         hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(384), 0, g.stream, (const float*)g.poly[k],
                            (const float*)g.flow[k], g.vs, g.vs0, np);
     } else {
