@@ -270,6 +270,16 @@ __device__ __forceinline__ void st_off(void* __restrict__ base, unsigned byte_of
     *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off) = v;
 }
 
+// non-temporal store: D is written once and read once by the next kernel.  Measured A/B on one box, 3 rounds
+// each, D stores and D loads non-temporal vs plain: k_hscan<320> 0.146 -> 0.121 ms, k_uv<320> 0.288 -> 0.300 ms,
+// 59.3 k -> 61.4 k frames/s with 3 clips in flight (loads alone: hscan 0.115 ms but 58.5 k frames/s; the same
+// treatment of the preprocess input loads LOST 4 %)
+template <typename T>
+__device__ __forceinline__ void st_off_nt(void* __restrict__ base, unsigned byte_off, T v)
+{
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(static_cast<char*>(base) + byte_off));
+}
+
 __device__ __forceinline__ void ne_load(const float* __restrict__ R, const float* __restrict__ flow, unsigned r0base,
                                         unsigned flbase, int x, int y, int w, int plane, NeIn& in)
 {
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
                             const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
                             const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
 #pragma unroll
-                            for (int c = 0; c < 5; c++) st_off<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, dv[i][c]);
+                            for (int c = 0; c < 5; c++) st_off_nt<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, dv[i][c]);
                         }
                         if (head) {
 #pragma unroll
@@ -536,8 +546,8 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
                 const unsigned t1 = dbase + ((unsigned)(y1 >> 6) * 5 * XCH) * 512u + (y1 & 63) * 8 + sw1;
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    st_off<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, d0[c]);
-                    st_off<double>(D16, (t1 + (unsigned)c * XCH * 512u) * 8u, d1[c]);
+                    st_off_nt<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, d0[c]);
+                    st_off_nt<double>(D16, (t1 + (unsigned)c * XCH * 512u) * 8u, d1[c]);
                 }
             }
             if (head) {
@@ -624,7 +634,7 @@ __device__ __forceinline__ void chunk_issue(ChunkRegs& r, const double* tiles, i
     for (int c = 0; c < 5; c++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            r.v[c][i] = *reinterpret_cast<const dbl2*>(tiles + ((int64_t)c * xch + xc) * 512 + i * 128 + lane * 2);
+            r.v[c][i] = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(tiles + ((int64_t)c * xch + xc) * 512 + i * 128 + lane * 2));
 }
 
 __device__ __forceinline__ void chunk_commit(const ChunkRegs& r, double (*buf)[512], int lane)
