@@ -156,11 +156,11 @@ __global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, in
     // interleaved [y][x][5] (cv2's own layout): k_uv gathers all five coefficients of a pixel and of
     // its right-hand neighbour as ten consecutive floats
     float* out = R + ((int64_t)f * w * h + y * w + x) * 5;
-    out[0] = (float)(b3 * C->ig11);
-    out[1] = (float)(b2 * C->ig11);
-    out[2] = (float)(b1 * C->ig03 + b5 * C->ig33);
-    out[3] = (float)(b1 * C->ig03 + b4 * C->ig33);
-    out[4] = (float)(b6 * C->ig55);
+    __builtin_nontemporal_store((float)(b3 * C->ig11), out + 0);
+    __builtin_nontemporal_store((float)(b2 * C->ig11), out + 1);
+    __builtin_nontemporal_store((float)(b1 * C->ig03 + b5 * C->ig33), out + 2);
+    __builtin_nontemporal_store((float)(b1 * C->ig03 + b4 * C->ig33), out + 3);
+    __builtin_nontemporal_store((float)(b6 * C->ig55), out + 4);
 }
 
 // ---------------------------------------------------------------------------------------
