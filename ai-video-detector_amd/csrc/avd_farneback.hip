@@ -350,17 +350,20 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
 // ---------------------------------------------------------------------------------------
 // k_uvp: the same computation as a producer / consumer workgroup.  Per row of a strip, ~80 % of the
 // instructions (loads, bilinear gather, normal equations) do not depend on the previous row; only five
-// double adds per row chain.  A strip gets NPROD + 1 waves:
-//   waves 1..NPROD (producers): wave w evaluates the normal equations of entry NPROD*k+(w-1) in phase k
-//       (entry e = image row min(e, H-1); entries 0..6 initialise the box, entry y+7 enters at step y).
-//       They only LOAD: loads and stores share one in-order vmcnt on this hardware, so a wave that also
-//       stores waits for its own store acknowledgements whenever it waits for a prefetched load;
-//   wave 0 (consumer): walks the entries in order, keeps the last 16 rows in a register ring, runs the
-//       five running double sums, exchanges vsum(x+7)/vsum(x-8) through a wave-private LDS row, and is
-//       the only wave that STORES (D tiles, vsum columns 0..6) -- it never waits on memory.
-// Hand-off through double-buffered LDS (M rows, float), ONE barrier per NPROD rows.  Producers
-// software-pipeline their own entries (stride NPROD rows): flow/R0 loads three phases ahead, gathers
-// one phase ahead, static register slots; their steps have no branches around memory operations.
+// double adds per row chain.  A strip gets NPROD + 2 waves:
+//   waves 2..NPROD+1 (producers): wave w evaluates the normal equations of entry NPROD*k+(w-2) in phase k
+//       (entry e = image row min(e, H-1); entries 0..6 initialise the box, entry y+7 enters at step y) and
+//       writes the row into a 24-slot ring in LDS.  They only LOAD: loads and stores share one in-order
+//       vmcnt on this hardware, so a wave that also stores waits for its own store acknowledgements
+//       whenever it waits for a prefetched load;
+//   wave 0 (summer): the only sequential part -- per entry, vsum += entering row - leaving row (both read
+//       from the ring, all LDS reads of a phase first), publishes the vsum rows of the phase in LDS;
+//   wave 1 (storer): one phase later forms D = vsum(x+7) - vsum(x-8) from those rows and is the only wave
+//       that STORES (D tiles, vsum columns 0..6) -- it never waits on memory.
+// (s_memtime stamps: with a single consumer wave doing sums, D and stores, that wave was the critical path.)
+// ONE barrier per NPROD rows.  Producers software-pipeline their own entries (stride NPROD rows): flow/R0
+// loads three phases ahead, gathers one phase ahead, static register slots; their steps have no branches
+// around memory operations.  50 KiB of LDS = 3 workgroups per CU by LDS, 2 by registers (6 waves x 104 VGPRs).
 // ---------------------------------------------------------------------------------------
 template <int W, int NPROD>
 __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
