@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -42,7 +43,7 @@ def build(force: bool = False) -> str:
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "avd.h"))
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
-        subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True)
+        subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True, stdout=sys.stderr)   # keep stdout clean (bench.py prints one JSON line)
     return SO_PATH
 
 

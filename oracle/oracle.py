@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -29,7 +30,7 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "avd_oracle.c")
     stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
     if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True, stdout=sys.stderr)
     return _SO
 
 
