@@ -602,6 +602,11 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
             float a0[5], a1[5];
             ne_finish(in[j0], g[j0 & 3], x, ra, W, H, a0);
             ne_finish(in[j1], g[j1 & 3], x, rb, W, H, a1);
+            // The refills must not be scheduled above the arithmetic that consumes the old contents of their slots:
+            // otherwise old and new values of a slot are live together, the new ones get other registers, and the
+            // loop back-edge becomes ~60 v_mov of just-loaded registers behind an s_waitcnt vmcnt(7) -- a drain of
+            // the whole software pipeline every four steps (seen in the ISA).
+            __builtin_amdgcn_sched_barrier(0);
             // refill the slots just consumed: gathers two steps ahead, inputs four steps ahead
             ne_gather(R, r1base, in[(j0 + 4) & 7], x, min(ra + 4, H - 1), W, H, plane, g[j0 & 3]);
             ne_gather(R, r1base, in[(j1 + 4) & 7], x, min(rb + 4, H - 1), W, H, plane, g[j1 & 3]);
