@@ -17,12 +17,18 @@ from avd_hip import analyzer as _analyzer
 from avd_hip import sources as _sources
 from avd_hip.timeline import records_to_result, sample_step
 
-_DEVICE = int(os.getenv("AVD_DEVICE", "0"))
-_CHUNK = int(os.getenv("AVD_CHUNK_FRAMES", "64"))      # sampled frames per HIP call (host memory bound)
-_SAMPLES_PER_SECOND = float(os.getenv("AVD_SAMPLES_PER_SECOND", "2"))   # extension knob; 2 = the reference (video.py:19)
+def _settings():
+    """Environment knobs, read per call (a service may be reconfigured without a restart; tests set them per case):
+    AVD_DEVICE            HIP device index (default 0)
+    AVD_CHUNK_FRAMES      sampled frames per HIP call (bounds host memory; default 64)
+    AVD_SAMPLES_PER_SECOND  extension knob, 2 = the reference's hard-coded sampling (video.py:19); 8 = the dense
+                          sampling of BASELINE.json configs[3]"""
+    return (int(os.getenv("AVD_DEVICE", "0")), int(os.getenv("AVD_CHUNK_FRAMES", "64")),
+            float(os.getenv("AVD_SAMPLES_PER_SECOND", "2")))
 
 
 def analyze(path: str, meta: dict):
+    device, chunk, per_second = _settings()
     src = _sources.open_source(path)
     if src is None:
         return {"timeline": [], "summary": {}, "timeline_ai": []}
@@ -31,7 +37,7 @@ def analyze(path: str, meta: dict):
         w = meta.get("width") or int(src.width or 0)
         h = meta.get("height") or int(src.height or 0)
         duration = meta.get("duration") or (src.frame_count / fps if fps > 0 else 0.0)
-        step = sample_step(fps, _SAMPLES_PER_SECOND)
+        step = sample_step(fps, per_second)
 
         seen = {}
 
@@ -40,7 +46,9 @@ def analyze(path: str, meta: dict):
                 seen.setdefault("npix", int(fr.shape[0]) * int(fr.shape[1]))
                 yield fr
 
-        rec = _analyzer.FrameAnalyzer(device=_DEVICE, chunk=_CHUNK).records_stream(frames())
+        # one pooled context for the duration of the request (bounded pool: api.py:133 runs this on worker threads)
+        with _analyzer.default_pool().borrow(device) as ctx:
+            rec = _analyzer.FrameAnalyzer(chunk=chunk, ctx=ctx).records_stream(frames())
     finally:
         src.close()
     return records_to_result(rec, seen.get("npix", 0), w, h, fps, duration)

@@ -9,5 +9,5 @@
   dist      frame-parallel sharding across ranks + record all-gather (RCCL / gloo)
 """
 from ._lib import AvdError, Context, RECORD_DTYPE, build, load  # noqa: F401
-from .analyzer import ClipsInFlight, FrameAnalyzer, analyze_frames  # noqa: F401
+from .analyzer import ClipsInFlight, ContextPool, FrameAnalyzer, analyze_frames, default_pool  # noqa: F401
 from .timeline import records_to_result, sample_step  # noqa: F401

@@ -23,7 +23,8 @@ SMALL, HASH = 320, 32
 EXPORTS = (
     "avd_abi_version", "avd_create", "avd_destroy", "avd_last_error",
     "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
-    "avd_analyze_frames_async", "avd_synchronize", "avd_timer_start", "avd_timer_stop",
+    "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
+    "avd_timer_start", "avd_timer_stop",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
 
@@ -90,6 +91,8 @@ def load() -> C.CDLL:
     L.avd_analyze_frames.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp]
     L.avd_analyze_frames_async.argtypes = L.avd_analyze_frames.argtypes
     L.avd_synchronize.argtypes = [vp]
+    L.avd_wait_stream.argtypes = [vp, vp]
+    L.avd_release_workspace.argtypes = [vp]
     L.avd_timer_start.argtypes = [vp]
     L.avd_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.avd_set_profiling.argtypes = [vp, C.c_int]
@@ -142,17 +145,27 @@ class Context:
             raise AvdError(f"avd status {rc}: {msg.decode() if msg else ''}")
 
     # -- buffers: numpy (host) or torch-ROCm tensors (device) ----------------------------
-    @staticmethod
-    def _frames_ptr(frames):
+    def _after_torch_stream(self, t):
+        """A device tensor may still be being written by torch's current stream (a fresh result, the copy kernel of
+        ``.contiguous()``); the context launches on its own non-blocking stream, so order the two with an event
+        (no host synchronisation).  The caller keeps the tensor alive until the work has been drained."""
+        import torch
+        if t.device.index is not None and t.device.index != self.device:
+            raise ValueError(f"tensor lives on cuda:{t.device.index}, context on device {self.device}")
+        self._check(self._L.avd_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
+
+    def _frames_ptr(self, frames):
         """-> (ptr, mem, n, h, w, row_stride, frame_stride, keepalive)"""
         if _is_torch_tensor(frames):
             t = frames
             if t.dim() != 4 or t.shape[-1] != 3 or str(t.dtype) != "torch.uint8":
                 raise ValueError("frames must be uint8[N,H,W,3] (BGR)")
-            if t.stride(-1) != 1 or t.stride(-2) != 3:
-                t = t.contiguous()
             n, h, w, _ = t.shape
+            if t.stride(-1) != 1 or t.stride(-2) != 3 or t.stride(1) < 3 * w or (n > 1 and t.stride(0) < t.stride(1) * h):
+                t = t.contiguous()
             mem = AVD_MEM_DEVICE if t.is_cuda else AVD_MEM_HOST
+            if t.is_cuda:
+                self._after_torch_stream(t)
             fs = t.stride(0) if n > 1 else h * t.stride(1)
             return t.data_ptr(), mem, n, h, w, t.stride(1), fs, t
         a = np.asarray(frames)
@@ -178,6 +191,8 @@ class Context:
     def farneback_pairs(self, small, want_flow: bool = False):
         if _is_torch_tensor(small):
             t = small.contiguous()
+            if t.is_cuda:
+                self._after_torch_stream(t)
             ptr, mem, n, keep = t.data_ptr(), (AVD_MEM_DEVICE if t.is_cuda else AVD_MEM_HOST), t.shape[0], t
         else:
             a = np.ascontiguousarray(small, dtype=np.uint8)
@@ -201,10 +216,17 @@ class Context:
         ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
         assert rec.dtype == RECORD_DTYPE and rec.size >= n and rec.flags.c_contiguous
         self._check(self._L.avd_analyze_frames_async(self._h, ptr, mem, n, h, w, rs, fs, rec.ctypes.data))
-        return keep
+        return keep          # the buffer the kernels read: the caller holds it until synchronize()
 
     def synchronize(self):
         self._check(self._L.avd_synchronize(self._h))
+
+    def wait_stream(self, stream_handle: int = 0):
+        """Order this context's stream behind everything already enqueued on another HIP stream (raw handle)."""
+        self._check(self._L.avd_wait_stream(self._h, C.c_void_p(stream_handle)))
+
+    def release_workspace(self):
+        self._check(self._L.avd_release_workspace(self._h))
 
     def timer_start(self):
         self._check(self._L.avd_timer_start(self._h))

@@ -7,6 +7,8 @@ reference does per sampled frame between ``cap.retrieve()`` and ``timeline_ai.ap
 from __future__ import annotations
 
 import collections
+import contextlib
+import os
 import threading
 from typing import Iterable, Iterator, Optional, Tuple
 
@@ -15,24 +17,112 @@ import numpy as np
 from . import _lib
 from .timeline import records_to_result
 
-_tls = threading.local()
+class ContextPool:
+    """Bounded pool of avd contexts for a threaded service.
+
+    Reference api.py:133 runs the analyzer on ``asyncio.to_thread`` workers (up to 32 threads in the default
+    executor) and a context is not re-entrant, so every request borrows one for its duration.  A context holds
+    about 1.5 GB of HBM scratch after a 120-frame 1080p clip, so the pool is bounded: at most ``max_contexts``
+    exist per device (further requests wait for one -- three or four clips in flight already saturate the GPU,
+    DESIGN.md 4.5), and only ``keep_warm`` idle ones keep their workspace; the others give it back
+    (``avd_release_workspace``) and re-reserve it on their next use.
+    """
+
+    def __init__(self, max_contexts: Optional[int] = None, keep_warm: Optional[int] = None):
+        self.max_contexts = max(1, int(max_contexts if max_contexts is not None else os.getenv("AVD_MAX_CONTEXTS", "4")))
+        self.keep_warm = max(0, int(keep_warm if keep_warm is not None else os.getenv("AVD_WARM_CONTEXTS", "2")))
+        self._cv = threading.Condition()
+        self._warm = {}            # device -> idle contexts that still hold their workspace, most recently used last
+        self._cold = {}            # device -> idle contexts whose workspace was given back
+        self._count = {}           # device -> contexts created
+
+    @contextlib.contextmanager
+    def borrow(self, device: int = 0):
+        ctx = self._take(device)
+        try:
+            yield ctx
+        finally:
+            self._give(device, ctx)
+
+    def _take(self, device):
+        with self._cv:
+            while True:
+                warm, cold = self._warm.setdefault(device, []), self._cold.setdefault(device, [])
+                if warm:
+                    return warm.pop()                      # the most recently used one
+                if cold:
+                    return cold.pop()
+                if self._count.get(device, 0) < self.max_contexts:
+                    self._count[device] = self._count.get(device, 0) + 1
+                    break
+                self._cv.wait()
+        try:
+            return _lib.Context(device)
+        except BaseException:
+            with self._cv:
+                self._count[device] -= 1
+                self._cv.notify()
+            raise
+
+    def _give(self, device, ctx):
+        trim = []
+        with self._cv:
+            warm = self._warm.setdefault(device, [])
+            warm.append(ctx)
+            while len(warm) > self.keep_warm:
+                trim.append(warm.pop(0))                   # least recently used
+            if warm:
+                self._cv.notify()
+        for c in trim:                                     # outside the lock: this synchronises the context's stream
+            try:
+                c.release_workspace()
+            finally:
+                with self._cv:
+                    self._cold.setdefault(device, []).append(c)
+                    self._cv.notify()
+
+    def stats(self, device: int = 0):
+        with self._cv:
+            return {"created": self._count.get(device, 0), "warm": len(self._warm.get(device, [])),
+                    "cold": len(self._cold.get(device, []))}
+
+    def close(self):
+        with self._cv:
+            ctxs = [c for d in (self._warm, self._cold) for lst in d.values() for c in lst]
+            self._warm.clear()
+            self._cold.clear()
+            self._count.clear()
+        for c in ctxs:
+            c.close()
 
 
-def thread_context(device: int = 0) -> "_lib.Context":
-    """One avd_ctx per (thread, device): reference api.py:133 runs the analyzer on worker
-    threads (asyncio.to_thread), so contexts are never shared between threads."""
-    cache = getattr(_tls, "ctx", None)
-    if cache is None:
-        cache = _tls.ctx = {}
-    if device not in cache:
-        cache[device] = _lib.Context(device)
-    return cache[device]
+_pool = ContextPool()
+
+
+def default_pool() -> ContextPool:
+    return _pool
 
 
 class FrameAnalyzer:
+    """Frames -> records on ONE context.  Pass ``ctx`` (tests, batch jobs) or borrow one from a pool
+    (``with default_pool().borrow(device) as ctx: FrameAnalyzer(ctx=ctx)...``), which is what the drop-in
+    ``app.analyzers.video.analyze`` does per request."""
+
     def __init__(self, device: int = 0, chunk: int = 64, ctx: Optional["_lib.Context"] = None):
-        self.ctx = ctx or thread_context(device)
+        self._own = ctx is None
+        self.ctx = ctx or _lib.Context(device)
         self.chunk = max(2, int(chunk))
+
+    def close(self):
+        if self._own and self.ctx is not None:
+            self.ctx.close()
+        self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
     # -- whole stack resident (numpy host array or torch-ROCm tensor) ----------------------
     def records(self, frames) -> np.ndarray:
@@ -92,8 +182,10 @@ class ClipsInFlight:
             raise RuntimeError("ClipsInFlight.submit: all contexts busy, drain() first")
         slot = self._free.popleft()
         rec = np.zeros(int(frames.shape[0]), _lib.RECORD_DTYPE)
-        self.ctxs[slot].analyze_frames_async(frames, rec)
-        self._pending.append((slot, tag, rec, frames))
+        # `keep` is the buffer the kernels actually read (the input itself, or a contiguous copy of it): it must
+        # stay allocated until the clip has been drained, or torch's caching allocator may hand it out again
+        keep = self.ctxs[slot].analyze_frames_async(frames, rec)
+        self._pending.append((slot, tag, rec, (frames, keep)))
 
     def drain(self) -> Tuple[object, np.ndarray]:
         """Wait for the OLDEST clip in flight -> (tag, records)."""
@@ -113,4 +205,5 @@ class ClipsInFlight:
 
 def analyze_frames(frames, meta: Optional[dict] = None, device: int = 0) -> dict:
     """Convenience wrapper: the frames-level analogue of reference ``video.analyze``."""
-    return FrameAnalyzer(device).analyze(frames, meta or {})
+    with default_pool().borrow(device) as ctx:
+        return FrameAnalyzer(ctx=ctx).analyze(frames, meta or {})

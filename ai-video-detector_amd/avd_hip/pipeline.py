@@ -10,7 +10,8 @@
 
 The HTTP routes themselves (upload spooling, yt-dlp, CORS, error bodies; api.py:213-279) are
 control plane and stay the reference's: run the reference ``api.py`` with this package first on
-PYTHONPATH and every route keeps working, backed by the MI355X analyzer.
+PYTHONPATH (the ``app`` package extends its search path to the reference checkout, so
+``audio`` / ``meta`` still come from there) and every route keeps working, backed by the MI355X analyzer.
 """
 from __future__ import annotations
 
@@ -27,45 +28,57 @@ from app.analyzers import video as video_an
 META_KEYS = ("width", "height", "fps", "duration", "bit_rate", "vcodec", "acodec", "format_name")
 
 
+def _ffprobe_json(path: str) -> Dict[str, Any]:
+    """Raw ffprobe report, or {} when ffprobe is absent / fails / times out (api.py:46-56)."""
+    if not shutil.which("ffprobe"):
+        return {}
+    fields = "format=bit_rate,duration,format_name:stream=codec_name,codec_type,width,height,r_frame_rate"
+    try:
+        report = subprocess.check_output(["ffprobe", "-v", "error", "-show_entries", fields, "-of", "json", path],
+                                         text=True, stderr=subprocess.DEVNULL, timeout=30)
+        return json.loads(report)
+    except Exception:          # noqa: BLE001 -- the reference swallows everything here
+        return {}
+
+
+def _frame_rate(text) -> float:
+    """'30000/1001' -> 29.97; the denominator is floored at 1 and anything unparsable is 0 (api.py:67-72)."""
+    try:
+        num, den = (text or "0/1").split("/")
+        return float(num) / max(1.0, float(den))
+    except Exception:          # noqa: BLE001
+        return 0.0
+
+
 def probe_basic_meta(path: str) -> Dict[str, Any]:
-    """ffprobe-based container metadata with the reference's fallbacks (api.py:46-89): when
-    ffprobe is missing or fails every field is zero / None and the analyzers fall back to the
-    frame source's own properties."""
-    info: Dict[str, Any] = {}
-    if shutil.which("ffprobe"):
+    """Container metadata with the reference's fallbacks (api.py:58-89): every field is zero / None when
+    ffprobe cannot be used, and the analyzers then fall back to the frame source's own properties.
+
+    Stream selection as the reference's loop does it: video streams are taken in order until one reports a
+    non-zero width (that one wins; leading zero-width streams are overwritten), the first audio stream that
+    is seen while no audio codec is known gives ``acodec``.  A ``bit_rate`` that is not a number raises, as it
+    does in the reference (the request then fails with the service's 500 body)."""
+    report = _ffprobe_json(path)
+    meta: Dict[str, Any] = {"width": 0, "height": 0, "fps": 0.0, "duration": 0.0, "bit_rate": 0,
+                            "vcodec": None, "acodec": None, "format_name": None}
+    for stream in report.get("streams") or ():
+        kind = stream.get("codec_type")
+        if kind == "video" and not meta["width"]:
+            meta["width"] = int(float(stream.get("width") or 0))
+            meta["height"] = int(float(stream.get("height") or 0))
+            meta["fps"] = _frame_rate(stream.get("r_frame_rate"))
+            meta["vcodec"] = stream.get("codec_name")
+        elif kind == "audio" and not meta["acodec"]:
+            meta["acodec"] = stream.get("codec_name")
+    container = report.get("format")
+    if container:
+        meta["bit_rate"] = int(float(container.get("bit_rate") or 0))
+        meta["format_name"] = container.get("format_name")
         try:
-            out = subprocess.check_output(
-                ["ffprobe", "-v", "error", "-show_entries",
-                 "format=bit_rate,duration,format_name:stream=codec_name,codec_type,width,height,r_frame_rate",
-                 "-of", "json", path], text=True, stderr=subprocess.DEVNULL, timeout=30)
-            info = json.loads(out)
-        except Exception:
-            info = {}
-    width = height = fps = 0.0
-    vcodec = acodec = None
-    duration = 0.0
-    for s in info.get("streams") or []:
-        if s.get("codec_type") == "video" and not width:
-            width = float(s.get("width") or 0)
-            height = float(s.get("height") or 0)
-            try:
-                num, den = (s.get("r_frame_rate") or "0/1").split("/")
-                fps = float(num) / max(1.0, float(den))
-            except Exception:
-                fps = 0.0
-            vcodec = s.get("codec_name")
-        elif s.get("codec_type") == "audio" and not acodec:
-            acodec = s.get("codec_name")
-    bit_rate, fmt = 0, None
-    if info.get("format"):
-        bit_rate = int(float(info["format"].get("bit_rate") or 0))
-        fmt = info["format"].get("format_name")
-        try:
-            duration = float(info["format"].get("duration") or 0.0)
-        except Exception:
-            duration = 0.0
-    return {"width": int(width), "height": int(height), "fps": fps, "duration": duration,
-            "bit_rate": bit_rate, "vcodec": vcodec, "acodec": acodec, "format_name": fmt}
+            meta["duration"] = float(container.get("duration") or 0.0)
+        except Exception:      # noqa: BLE001
+            meta["duration"] = 0.0
+    return meta
 
 
 def _tlen(meta: dict) -> int:
@@ -97,10 +110,25 @@ def safe_call(kind: str, fn: Callable[[str, dict], dict], path: str, meta: dict,
         return neutral, extra
 
 
+def _reference_forensic() -> Optional[Callable[[str], dict]]:
+    """``meta.forensic_summary`` of a reference checkout behind this package on sys.path (api.py:18,164), if any."""
+    try:
+        from app.analyzers import meta as meta_an       # resolved through the extended package path
+    except Exception:          # noqa: BLE001 -- no reference checkout: the key is simply absent
+        return None
+    return getattr(meta_an, "forensic_summary", None)
+
+
 def analyze_path(path: str, meta: Optional[dict] = None, *, audio_analyzer: Optional[Callable[[str, dict], dict]] = None,
                  video_analyzer: Optional[Callable[[str, dict], dict]] = None, source_url: Optional[str] = None,
-                 resolved_url: Optional[str] = None, debug: bool = False) -> Dict[str, Any]:
-    """The body of POST /analyze for one file (api.py:142-162), synchronous."""
+                 resolved_url: Optional[str] = None, debug: bool = False,
+                 forensic: Optional[Callable[[str], dict]] = None) -> Dict[str, Any]:
+    """The body of POST /analyze for one file (api.py:142-170), synchronous.
+
+    ``forensic``: the exiftool / C2PA summary is control-plane I/O outside this build; pass the reference's
+    ``meta.forensic_summary`` (or leave None: it is picked up automatically when a reference checkout sits behind
+    this package on sys.path).  As in api.py:163-169 a falsy summary adds no key, and an exception adds
+    ``forensic_error`` only in debug mode."""
     meta = dict(meta) if meta is not None else probe_basic_meta(path)
     for k in META_KEYS:
         meta.setdefault(k, None if k in ("vcodec", "acodec", "format_name") else 0)
@@ -110,7 +138,7 @@ def analyze_path(path: str, meta: Optional[dict] = None, *, audio_analyzer: Opti
     hints.update(a_hint)
     hints.update(v_hint)
     fused = fusion_an.fuse(audio, video, hints)
-    return {
+    out = {
         "ok": True,
         "meta": {**meta, "source_url": source_url, "resolved_url": resolved_url},
         "hints": hints,
@@ -120,3 +148,13 @@ def analyze_path(path: str, meta: Optional[dict] = None, *, audio_analyzer: Opti
         "timeline_binned": fused["timeline_binned"],
         "peaks": fused["peaks"],
     }
+    summarize = forensic if forensic is not None else _reference_forensic()
+    if summarize is not None:
+        try:
+            report = summarize(path)
+            if report:
+                out["forensic"] = report
+        except Exception:      # noqa: BLE001 -- api.py:167
+            if debug:
+                out["forensic_error"] = traceback.format_exc()
+    return out

@@ -83,6 +83,9 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
     Workspace& ws = ctx->ws;
     const bool geom_changed = ws.h != h || ws.w != w;
     if (geom_changed) {
+        // a failure anywhere below must force a full rebuild on the next call (the tables and band layout of the NEW
+        // geometry are installed before the buffers are sized for it)
+        ws.h = ws.w = 0; ws.cap_n = 0;
         LinearTab lt;
         AreaTab at;
         build_linear_tab(h, w, AVD_SMALL, AVD_SMALL, lt);
@@ -137,6 +140,7 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
     }
     if (geom_changed || n > ws.cap_n) {
         const int cap = std::max(n, 1);
+        ws.cap_n = 0;                                  // not valid again until every buffer below exists
         if (int e = dev_alloc(ctx, ws.d_small, (size_t)cap * AVD_NPIX)) return e;
         if (int e = dev_alloc(ctx, ws.d_rowbuf, (size_t)cap * h * AVD_HASH)) return e;
         if (int e = dev_alloc(ctx, ws.d_area, (size_t)cap * 1024)) return e;
@@ -253,15 +257,17 @@ static int stage_input(avd_ctx* ctx, const uint8_t* src, int mem, size_t bytes, 
 
 static void stage_mark(avd_ctx* ctx, int i)
 {
-    if (ctx->profiling) (void)hipEventRecord(ctx->stage_ev[i], ctx->stream);
+    if (!ctx->profiling) return;
+    if (i == 0) ctx->stage_marks = 0;
+    if (hipEventRecord(ctx->stage_ev[i], ctx->stream) == hipSuccess) ctx->stage_marks++;
 }
 
-// ---- C-ABI ------------------------------------------------------------------------------
-extern "C" {
+// ---- entry-point bodies (wrapped by the extern "C" functions at the end of the file) -----------------
+static void impl_destroy(avd_ctx* ctx);
+static int impl_synchronize(avd_ctx* ctx);
 
-int avd_abi_version(void) { return AVD_ABI_VERSION; }
 
-int avd_create(int device_id, avd_ctx** out)
+static int impl_create(int device_id, avd_ctx** out)
 {
     if (!out) return AVD_ERR_ARG;
     *out = nullptr;
@@ -273,7 +279,8 @@ int avd_create(int device_id, avd_ctx** out)
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
     for (int i = 0; ok && i < 12; i++) ok = hipEventCreate(&ctx->kern_ev[i]) == hipSuccess;
     if (ok) {
@@ -284,12 +291,12 @@ int avd_create(int device_id, avd_ctx** out)
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
              hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (!ok) { avd_destroy(ctx); return AVD_ERR_DEVICE; }
+    if (!ok) { impl_destroy(ctx); return AVD_ERR_DEVICE; }
     *out = ctx;
     return AVD_OK;
 }
 
-void avd_destroy(avd_ctx* ctx)
+static void impl_destroy(avd_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -298,15 +305,14 @@ void avd_destroy(avd_ctx* ctx)
     if (ctx->d_fbc) (void)hipFree(ctx->d_fbc);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kern_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
-const char* avd_last_error(const avd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-
-int avd_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+static int impl_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
                        int64_t row_stride, int64_t frame_stride,
                        uint8_t* small320, uint8_t* hash1024, int64_t* lap_sum, int64_t* lap_sumsq)
 {
@@ -335,7 +341,7 @@ int avd_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, 
     return AVD_OK;
 }
 
-int avd_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, int n,
+static int impl_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, int n,
                         float* flow_mean, float* flow_var, float* flow_out)
 {
     if (!ctx) return AVD_ERR_ARG;
@@ -350,7 +356,7 @@ int avd_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, int n,
     return AVD_OK;
 }
 
-int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+static int impl_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
                              int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
 {
     if (!ctx) return AVD_ERR_ARG;
@@ -358,7 +364,7 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
     if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
     if (n == 0) return AVD_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->pending_out) { if (int e = avd_synchronize(ctx)) return e; }     // a previous call was never drained
+    if (ctx->pending_out) { if (int e = impl_synchronize(ctx)) return e; }     // a previous call was never drained
     if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
     if (int e = avd_ws_reserve_fb(ctx, n)) return e;
     const uint8_t* d_bgr = nullptr;
@@ -384,7 +390,7 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
     return AVD_OK;
 }
 
-int avd_synchronize(avd_ctx* ctx)
+static int impl_synchronize(avd_ctx* ctx)
 {
     if (!ctx) return AVD_ERR_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -392,7 +398,7 @@ int avd_synchronize(avd_ctx* ctx)
         std::memcpy(ctx->pending_out, ctx->ws.h_rec, sizeof(avd_frame_record) * ctx->pending_n);
         ctx->pending_out = nullptr; ctx->pending_n = 0;
     }
-    if (ctx->profiling) {
+    if (ctx->profiling && ctx->stage_marks == 5) {
         // stages: 0 preprocess, 1 hash+hamming+records, 2 farneback+stats (3 reported as copy-out)
         for (int i = 0; i < 4; i++) {
             float ms = 0.f;
@@ -400,31 +406,32 @@ int avd_synchronize(avd_ctx* ctx)
         }
         // 4 / 5: mean duration of one k_uv<320> / k_hscan<320> launch (first segment of the last chunk)
         float sum[2] = {0.f, 0.f}; int cnt[2] = {0, 0};
-        for (int i = 0; i + 1 < ctx->kern_ev_used; i += 2) {
+        for (int i = 0; i + 1 < ctx->kern_ev_used; i += 2) {     // recorded by blur_iteration<320> of the drained call
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->kern_ev[i], ctx->kern_ev[i + 1]) == hipSuccess) { sum[(i >> 1) & 1] += ms; cnt[(i >> 1) & 1]++; }
         }
         for (int k = 0; k < 2; k++) ctx->stage_ms[4 + k] = cnt[k] ? sum[k] / cnt[k] : 0.f;
+        ctx->stage_marks = 0;                       // the events belong to the call that was just drained
     }
     return AVD_OK;
 }
 
-int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+static int impl_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
                        int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
 {
-    int rc = avd_analyze_frames_async(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records);
+    int rc = impl_analyze_frames_async(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records);
     if (rc) return rc;
-    return avd_synchronize(ctx);
+    return impl_synchronize(ctx);
 }
 
-int avd_timer_start(avd_ctx* ctx)
+static int impl_timer_start(avd_ctx* ctx)
 {
     if (!ctx) return AVD_ERR_ARG;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return AVD_OK;
 }
 
-int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms)
+static int impl_timer_stop(avd_ctx* ctx, float* elapsed_ms)
 {
     if (!ctx || !elapsed_ms) return AVD_ERR_ARG;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -433,21 +440,21 @@ int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms)
     return AVD_OK;
 }
 
-int avd_set_profiling(avd_ctx* ctx, int enable)
+static int impl_set_profiling(avd_ctx* ctx, int enable)
 {
     if (!ctx) return AVD_ERR_ARG;
     ctx->profiling = enable != 0;
     return AVD_OK;
 }
 
-int avd_stage_ms(avd_ctx* ctx, int stage, float* ms)
+static int impl_stage_ms(avd_ctx* ctx, int stage, float* ms)
 {
     if (!ctx || !ms || stage < 0 || stage > 5) return AVD_ERR_ARG;
     *ms = ctx->stage_ms[stage];
     return AVD_OK;
 }
 
-int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes)
+static int64_t impl_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes)
 {
     if (!ctx || !name || !out) return AVD_ERR_ARG;
     Workspace& ws = ctx->ws;
@@ -463,10 +470,11 @@ int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_by
     int k;
     if (std::strcmp(name, "area") == 0) { src = ws.d_area; bytes = (size_t)n * 1024; }
     else if (std::strcmp(name, "small") == 0) { src = ws.d_small; bytes = (size_t)n * AVD_NPIX; }
-    else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)n * (AVD_NPIX >> (2 * k)) * 4; }
-    else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)n * 5 * (AVD_NPIX >> (2 * k)) * 4; }
-    else if ((k = level("flow")) >= 0) { src = ws.d_flow[k]; bytes = (size_t)std::max(n - 1, 0) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
-    else if (std::strcmp(name, "vs0") == 0) { src = ws.d_vs0; bytes = (size_t)128 * 5 * AVD_SMALL * 8 * 8; }
+    // the Farneback scratch holds ONE chunk (kFbChunk pairs): for longer clips these are the last chunk's buffers
+    else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)std::min(n, kFbChunk + 1) * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)std::min(n, kFbChunk + 1) * 5 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("flow")) >= 0) { src = ws.d_flow[k]; bytes = (size_t)std::min(std::max(n - 1, 0), kFbChunk) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if (std::strcmp(name, "vs0") == 0) { src = ws.d_vs0; bytes = (size_t)kFbChunk * 5 * AVD_SMALL * 8 * 8; }
     else { ctx->err = "unknown debug buffer"; return AVD_ERR_ARG; }
     if (!src) { ctx->err = "buffer not allocated yet"; return AVD_ERR_ARG; }
     bytes = std::min(bytes, out_bytes);
@@ -474,6 +482,100 @@ int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_by
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
     return (int64_t)bytes;
+}
+
+// Wait for work the caller enqueued on ANOTHER stream (e.g. torch's current stream, which produced or is still
+// producing a device input) before anything submitted to this context afterwards: an event on the producer stream,
+// waited for by the context's stream.  A null handle names the legacy default stream.
+static int impl_wait_stream(avd_ctx* ctx, void* producer)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_in, (hipStream_t)producer));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+    return AVD_OK;
+}
+
+// Give the scratch memory back (a service keeps idle contexts cheap); the next call re-reserves it.
+static int impl_release_workspace(avd_ctx* ctx)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int e = impl_synchronize(ctx)) return e;
+    free_ws(ctx->ws);
+    return AVD_OK;
+}
+
+// Nothing may propagate across the C boundary: std::vector / std::string members of the context and the table
+// builders can throw std::bad_alloc (or length_error), so every entry point runs inside this guard.
+template <typename F>
+static int guarded(avd_ctx* ctx, F&& f) noexcept
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        if (ctx) { try { ctx->err = "out of host memory"; } catch (...) {} }
+        return AVD_ERR_NOMEM;
+    } catch (...) {
+        if (ctx) { try { ctx->err = "unexpected C++ exception"; } catch (...) {} }
+        return AVD_ERR_DEVICE;
+    }
+}
+
+// ---- C-ABI ------------------------------------------------------------------------------
+extern "C" {
+
+int avd_abi_version(void) { return AVD_ABI_VERSION; }
+
+const char* avd_last_error(const avd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int avd_create(int device_id, avd_ctx** out)
+{
+    return guarded(nullptr, [&] { return impl_create(device_id, out); });
+}
+
+void avd_destroy(avd_ctx* ctx)
+{
+    (void)guarded(nullptr, [&] { impl_destroy(ctx); return 0; });
+}
+
+int avd_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
+                       int64_t frame_stride, uint8_t* small320, uint8_t* hash1024, int64_t* lap_sum, int64_t* lap_sumsq)
+{
+    return guarded(ctx, [&] { return impl_preprocess_bgr(ctx, bgr, mem, n, h, w, row_stride, frame_stride, small320, hash1024, lap_sum, lap_sumsq); });
+}
+
+int avd_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, int n, float* flow_mean, float* flow_var, float* flow_out)
+{
+    return guarded(ctx, [&] { return impl_farneback_pairs(ctx, small320, mem, n, flow_mean, flow_var, flow_out); });
+}
+
+int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
+                             int64_t frame_stride, avd_frame_record* records)
+{
+    return guarded(ctx, [&] { return impl_analyze_frames_async(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records); });
+}
+
+int avd_synchronize(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_synchronize(ctx); }); }
+
+int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
+                       int64_t frame_stride, avd_frame_record* records)
+{
+    return guarded(ctx, [&] { return impl_analyze_frames(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records); });
+}
+
+int avd_wait_stream(avd_ctx* ctx, void* producer_stream) { return guarded(ctx, [&] { return impl_wait_stream(ctx, producer_stream); }); }
+int avd_release_workspace(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_release_workspace(ctx); }); }
+int avd_timer_start(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_timer_start(ctx); }); }
+int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms) { return guarded(ctx, [&] { return impl_timer_stop(ctx, elapsed_ms); }); }
+int avd_set_profiling(avd_ctx* ctx, int enable) { return guarded(ctx, [&] { return impl_set_profiling(ctx, enable); }); }
+int avd_stage_ms(avd_ctx* ctx, int stage, float* ms) { return guarded(ctx, [&] { return impl_stage_ms(ctx, stage, ms); }); }
+
+int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes)
+{
+    int64_t got = AVD_ERR_DEVICE;
+    const int rc = guarded(ctx, [&] { got = impl_debug_fetch(ctx, name, out, out_bytes); return 0; });
+    return rc ? rc : got;
 }
 
 }  // extern "C"

@@ -106,12 +106,14 @@ struct avd_ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_in = nullptr;                // avd_wait_stream: recorded on the caller's stream, waited for by ours
     avd_frame_record* pending_out = nullptr;   // caller buffer the pinned records are handed to in avd_synchronize
     int pending_n = 0;
     hipEvent_t stage_ev[5] = {};
     hipEvent_t kern_ev[12] = {};           // profiling: start/stop of the 3 k_uv<320> and 3 k_hscan<320> launches of a segment
     int kern_ev_used = 0;
     int profiling = 0;
+    int stage_marks = 0;                       // stage events recorded by the call in flight (5 = all of them)
     float stage_ms[6] = {};
     std::string err;
     Workspace ws;

@@ -105,6 +105,18 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
                              avd_frame_record* records);
 int avd_synchronize(avd_ctx* ctx);
 
+/* Stream ordering for AVD_MEM_DEVICE inputs.  A context launches on its own non-blocking stream, so device memory
+ * that another stream is still writing (e.g. torch's current stream: a freshly computed tensor, a .contiguous()
+ * copy, a decoder's colour-conversion kernel) must be ordered explicitly: everything enqueued on `producer_stream`
+ * (a hipStream_t passed as a plain pointer; NULL = the default stream) before this call completes before anything
+ * submitted to ctx afterwards starts.  No host synchronisation.  The caller keeps the input buffer alive until
+ * avd_synchronize / the blocking call returns. */
+int avd_wait_stream(avd_ctx* ctx, void* producer_stream);
+
+/* Free the context's scratch memory (about 1.5 GB after a 120-frame 1080p clip) but keep the context; the next
+ * call reserves it again.  For services that keep a pool of idle contexts. */
+int avd_release_workspace(avd_ctx* ctx);
+
 /* HIP-event timing of the work enqueued on ctx's stream between the two calls
  * (milliseconds).  avd_timer_stop synchronizes the stream. */
 int avd_timer_start(avd_ctx* ctx);

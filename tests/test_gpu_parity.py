@@ -204,29 +204,64 @@ def test_device_resident_inputs(ctx, oracle):
     assert np.array_equal(fm, rec["flow_mean"][1:]) and np.array_equal(fv, rec["flow_var"][1:])
 
 
-def test_two_threads_two_contexts(ctx):
-    """reference api.py:133 runs the analyzer on worker threads: one avd_ctx per thread, concurrently."""
+def test_worker_threads_borrow_pooled_contexts(ctx):
+    """reference api.py:133 runs the analyzer on worker threads: each request borrows a context from the bounded
+    pool for its duration; more threads than contexts, results identical to the session context's."""
     import threading
-    import avd_hip
     from avd_hip import analyzer
-    clips = [synth.make_clip(6, 120, 200, seed=s) for s in (51, 52)]
+    clips = [synth.make_clip(6, 120, 200, seed=s) for s in (51, 52, 53, 54)]
     want = [ctx.analyze_frames(c) for c in clips]
-    got = [None, None]
-    ctxs = [None, None]
+    pool = analyzer.ContextPool(max_contexts=2, keep_warm=1)
+    got = [None] * len(clips)
+    used = set()
 
     def work(i):
-        ctxs[i] = analyzer.thread_context(0)                  # thread-local context
         for _ in range(3):
-            got[i] = ctxs[i].analyze_frames(clips[i])
+            with pool.borrow(0) as c:
+                used.add(id(c))
+                got[i] = c.analyze_frames(clips[i])
 
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(clips))]
     for t in ts:
         t.start()
     for t in ts:
         t.join()
-    assert ctxs[0] is not ctxs[1] and ctxs[0] is not ctx
-    for i in range(2):
+    assert 1 <= len(used) <= 2 and pool.stats(0)["created"] == len(used)
+    for i in range(len(clips)):
         assert np.array_equal(got[i], want[i])
+    # a context whose workspace was released re-reserves it on its next use
+    with pool.borrow(0) as c:
+        c.release_workspace()
+        assert np.array_equal(c.analyze_frames(clips[0]), want[0])
+    pool.close()
+
+
+def test_non_contiguous_and_fresh_device_tensors(ctx, oracle):
+    """Device inputs that torch's CURRENT stream is still producing when the call is made: a planar tensor viewed
+    as interleaved (needs ``.contiguous()``: a copy kernel on torch's stream) and a freshly computed one.  The
+    context's own stream is ordered behind torch's with an event (avd_wait_stream), the contiguous temporary is
+    kept alive by the binding until the clip is drained."""
+    torch = pytest.importorskip("torch")
+    import avd_hip
+    clip = synth.make_clip(24, 1080, 1920, seed=61, dup_every=5)
+    want = ctx.analyze_frames(clip)
+    dev = torch.from_numpy(clip).to("cuda:0")
+    planar = dev.permute(0, 3, 1, 2).contiguous()                     # [N,3,H,W]
+    torch.cuda.synchronize()
+    view = planar.permute(0, 2, 3, 1)                                 # uint8[N,H,W,3] with channel stride H*W
+    assert not view.is_contiguous()
+    assert np.array_equal(ctx.analyze_frames(view), want)
+    # fresh: produced by kernels enqueued right before the call, no synchronisation in between
+    for _ in range(3):
+        fresh = (planar.to(torch.int16) + 0).to(torch.uint8).permute(0, 2, 3, 1)
+        assert np.array_equal(ctx.analyze_frames(fresh), want)
+    # asynchronous form: the temporary made by .contiguous() must survive until drain()
+    runner = avd_hip.ClipsInFlight(device=0, depth=2)
+    outs = list(runner.run((i, (planar + 0).permute(0, 2, 3, 1)) for i in range(4)))
+    assert all(np.array_equal(rec, want) for _, rec in outs)
+    # sliced rows / columns (strides, no copy needed) and a flipped batch (negative-free but re-ordered: copy)
+    sub = dev[:, 100:900, 64:1600]
+    assert np.array_equal(ctx.analyze_frames(sub), ctx.analyze_frames(np.ascontiguousarray(clip[:, 100:900, 64:1600])))
 
 
 def test_full_size_clip_properties(ctx, oracle):
