@@ -308,6 +308,33 @@ void avdo_flow_stats(const float* flow, int64_t npix, float* mean, float* var, f
     if (!mag_out) free(mag);
 }
 
+/* ---------- model switches (sensitivity analysis only; default 0 = the model of README.md) ----------
+ * The OpenCV build the reference runs on is not available here, so a few implementation choices of the wheel are
+ * modelled, not observed (oracle/README.md "open questions").  tests/test_oracle_sensitivity.py flips each choice
+ * and bounds how far it moves flow_mean / ai_susp against the 1e-4 parity tolerance. */
+static int g_model = 0;
+void avdo_set_model(int flags) { g_model = flags; }
+int avdo_get_model(void) { return g_model; }
+#define MODEL(bit) ((g_model & (bit)) != 0)
+
+static inline float mac(float a, float b, float c)     /* a*b + c as the Gaussian filters do it */
+{
+    if (MODEL(AVDO_MODEL_GAUSS_MULADD)) { float p = a * b; return p + c; }   /* -ffp-contract=off: two roundings */
+    return fmaf(a, b, c);
+}
+
+/* deterministic +-1 ulp pattern (what a different but equally valid operation order would produce) */
+static void ulp_jitter(float* a, size_t n, uint32_t seed)
+{
+    uint32_t st = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; i++) {
+        st = st * 1664525u + 1013904223u;
+        uint32_t r = st >> 30;                        /* 0,1: keep   2: +1 ulp   3: -1 ulp */
+        if (r == 2) a[i] = nextafterf(a[i], INFINITY);
+        else if (r == 3) a[i] = nextafterf(a[i], -INFINITY);
+    }
+}
+
 /* ---------- GaussianBlur on CV_32F (smooth.dispatch.cpp + filter.simd.hpp) ---------- */
 /* getGaussianKernel(n, sigma, CV_32F): bit-exact softdouble kernel then cast to float.
  * Restated in IEEE double with libm exp (softfloat's exp may differ in the last double
@@ -366,11 +393,11 @@ void avdo_gaussian_blur_f32(const float* src, int h, int w, int ksize, double si
             if (ksize == 3) {
                 float l = S[reflect101(x - 1, w)], r = S[reflect101(x + 1, w)];
                 float t = (l + r) * kc[1];
-                D[x] = fmaf(S[x], kc[0], t);
+                D[x] = mac(S[x], kc[0], t);
             } else {
                 float s = 0.f;
                 for (int k = 0; k < ksize; k++)
-                    s = fmaf(S[reflect101(x - half + k, w)], kbuf[k], s);
+                    s = mac(S[reflect101(x - half + k, w)], kbuf[k], s);
                 D[x] = s;
             }
         }
@@ -379,11 +406,11 @@ void avdo_gaussian_blur_f32(const float* src, int h, int w, int ksize, double si
         float* D = dst + (int64_t)y * w;
         for (int x = 0; x < w; x++) {
             float c = tmp[(int64_t)y * w + x];
-            float s = fmaf(c, kc[0], 0.f);
+            float s = mac(c, kc[0], 0.f);
             for (int k = 1; k <= half; k++) {
                 float a = tmp[(int64_t)reflect101(y + k, h) * w + x];
                 float b = tmp[(int64_t)reflect101(y - k, h) * w + x];
-                s = fmaf(a + b, kc[k], s);
+                s = mac(a + b, kc[k], s);
             }
             D[x] = s;
         }
@@ -449,7 +476,9 @@ int avdo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst,
             for (int dx = 0; dx < dw; dx++) {
                 int sx = xofs[dx] * cn;
                 for (int c = 0; c < cn; c++) {
-                    if (dx < xmax) D[dx * cn + c] = S[sx + c] * alpha[dx * 2] + S[sx + cn + c] * alpha[dx * 2 + 1];
+                    if (dx < xmax && MODEL(AVDO_MODEL_RESIZE_LERP))
+                        D[dx * cn + c] = S[sx + c] + (S[sx + cn + c] - S[sx + c]) * alpha[dx * 2 + 1];
+                    else if (dx < xmax) D[dx * cn + c] = S[sx + c] * alpha[dx * 2] + S[sx + cn + c] * alpha[dx * 2 + 1];
                     else D[dx * cn + c] = S[sx + c] * 1.f;
                 }
             }
@@ -457,7 +486,8 @@ int avdo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst,
         float b0 = beta[dy * 2], b1 = beta[dy * 2 + 1];
         const float *S0 = rows, *S1 = rows + (int64_t)dw * cn;
         float* D = dst + (int64_t)dy * dw * cn;
-        for (int x = 0; x < dw * cn; x++) D[x] = S0[x] * b0 + S1[x] * b1;
+        if (MODEL(AVDO_MODEL_RESIZE_LERP)) for (int x = 0; x < dw * cn; x++) D[x] = S0[x] + (S1[x] - S0[x]) * b1;
+        else for (int x = 0; x < dw * cn; x++) D[x] = S0[x] * b0 + S1[x] * b1;
     }
     free(rows); free(alpha); free(xofs);
     return 0;
@@ -732,6 +762,7 @@ int avdo_farneback(const uint8_t* prev, const uint8_t* next, int h, int w, float
         if (w * scale < min_size || h * scale < min_size) break;
     }
     levels = k;
+    if (MODEL(AVDO_MODEL_THREE_SCALES) && levels > 0) levels--;      /* "for (k = levels - 1 ...)" reading of the loop */
     size_t npix = (size_t)h * w;
     float* fimg = (float*)malloc(sizeof(float) * npix);
     float* blur = (float*)malloc(sizeof(float) * npix);
@@ -754,11 +785,13 @@ int avdo_farneback(const uint8_t* prev, const uint8_t* next, int h, int w, float
             avdo_resize_linear_f32(prevFlow, ph, pw, 2, flow, height, width);
             float mul = (float)(1. / pyr_scale);
             for (size_t t = 0; t < (size_t)width * height * 2; t++) flow[t] = flow[t] * mul;
+            if (MODEL(AVDO_MODEL_JITTER_FLOW)) ulp_jitter(flow, (size_t)width * height * 2, 77u + (uint32_t)k);
         }
         for (i = 0; i < 2; i++) {
             for (size_t t = 0; t < npix; t++) fimg[t] = (float)img[i][t];
             avdo_gaussian_blur_f32(fimg, h, w, smooth_sz, sigma, blur);
             avdo_resize_linear_f32(blur, h, w, 1, I, height, width);
+            if (MODEL(AVDO_MODEL_JITTER_PYRAMID)) ulp_jitter(I, (size_t)width * height, 31u * (uint32_t)k + (uint32_t)i);
             avdo_poly_exp(I, height, width, poly_n, poly_sigma, R[i]);
         }
         avdo_update_matrices(R[0], R[1], flow, M, height, width, 0, height);

@@ -28,7 +28,8 @@ HASH = 32            # video.py:36
 def build(force: bool = False) -> str:
     """Compile oracle/avd_oracle.c with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "avd_oracle.c")
-    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    hdr = os.path.join(_HERE, "avd_oracle.h")
+    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True, stdout=sys.stderr)
     return _SO
@@ -62,12 +63,34 @@ def lib() -> C.CDLL:
         L.avdo_preprocess_bgr.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                           u8p, u8p, i64p, i64p]
         L.avdo_farneback_pairs.argtypes = [u8p, C.c_int, f32p, f32p]
+        L.avdo_set_model.argtypes = [C.c_int]
+        L.avdo_set_model.restype = None
+        L.avdo_get_model.restype = C.c_int
         for name in ("avdo_resize_area_u8", "avdo_resize_linear_u8", "avdo_farneback",
                      "avdo_gaussian_kernel_f32", "avdo_resize_linear_f32",
                      "avdo_preprocess_bgr", "avdo_farneback_pairs"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
+
+
+# model switches of avd_oracle.h (sensitivity analysis of the open questions, oracle/README.md)
+MODEL_GAUSS_MULADD, MODEL_JITTER_PYRAMID, MODEL_JITTER_FLOW, MODEL_THREE_SCALES, MODEL_RESIZE_LERP = 1, 2, 4, 8, 16
+
+
+class model:
+    """``with oracle.model(flags): ...`` runs the oracle with the given modelled choices flipped."""
+
+    def __init__(self, flags: int):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        self.saved = lib().avdo_get_model()
+        lib().avdo_set_model(self.flags)
+        return self
+
+    def __exit__(self, *a):
+        lib().avdo_set_model(self.saved)
 
 
 def _p(a: np.ndarray, t):
