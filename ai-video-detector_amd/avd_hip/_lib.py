@@ -24,7 +24,7 @@ EXPORTS = (
     "avd_abi_version", "avd_create", "avd_destroy", "avd_last_error",
     "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
     "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
-    "avd_timer_start", "avd_timer_stop",
+    "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
 
@@ -96,6 +96,7 @@ def load() -> C.CDLL:
     L.avd_timer_start.argtypes = [vp]
     L.avd_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.avd_set_profiling.argtypes = [vp, C.c_int]
+    L.avd_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.avd_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.avd_debug_fetch.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.avd_debug_fetch.restype = C.c_int64
@@ -235,6 +236,10 @@ class Context:
         ms = C.c_float()
         self._check(self._L.avd_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def set_option(self, name: str, value: int):
+        """Tuning / test switches, e.g. ``set_option("fb_fused", 0)`` selects the two-kernel Farneback path."""
+        self._check(self._L.avd_set_option(self._h, name.encode(), int(value)))
 
     def set_profiling(self, on: bool):
         self._check(self._L.avd_set_profiling(self._h, int(bool(on))))

@@ -287,6 +287,7 @@ static int impl_create(int device_id, avd_ctx** out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->num_cus = prop.multiProcessorCount;
+        if (const char* e = std::getenv("AVD_FB_FUSED")) ctx->fb_fused = (int)std::strtol(e, nullptr, 0) & 0xF;
         build_fb_consts(ctx->fbc);
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
              hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;
@@ -506,6 +507,15 @@ static int impl_release_workspace(avd_ctx* ctx)
     return AVD_OK;
 }
 
+// Tuning / test switches.  "fb_fused": bit k set = pyramid level k (0 = 320x320) runs the fused level kernel.
+static int impl_set_option(avd_ctx* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return AVD_ERR_ARG;
+    if (std::strcmp(name, "fb_fused") == 0) { ctx->fb_fused = value & 0xF; return AVD_OK; }
+    ctx->err = std::string("unknown option: ") + name;
+    return AVD_ERR_ARG;
+}
+
 // Nothing may propagate across the C boundary: std::vector / std::string members of the context and the table
 // builders can throw std::bad_alloc (or length_error), so every entry point runs inside this guard.
 template <typename F>
@@ -568,6 +578,7 @@ int avd_wait_stream(avd_ctx* ctx, void* producer_stream) { return guarded(ctx, [
 int avd_release_workspace(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_release_workspace(ctx); }); }
 int avd_timer_start(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_timer_start(ctx); }); }
 int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms) { return guarded(ctx, [&] { return impl_timer_stop(ctx, elapsed_ms); }); }
+int avd_set_option(avd_ctx* ctx, const char* name, int value) { return guarded(ctx, [&] { return impl_set_option(ctx, name, value); }); }
 int avd_set_profiling(avd_ctx* ctx, int enable) { return guarded(ctx, [&] { return impl_set_profiling(ctx, enable); }); }
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms) { return guarded(ctx, [&] { return impl_stage_ms(ctx, stage, ms); }); }
 

@@ -19,20 +19,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include "avd_internal.h"
+#include "avd_fb_device.h"
 
 #pragma clang fp contract(off)
 
 namespace {
 
 constexpr int S = AVD_SMALL;
-
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ int floor_f(float v) { int i = (int)v; return i - (i > v); }
 
 // ---------------------------------------------------------------------------------------
 // Gaussian pyramid level K (scale 2^-K): GaussianBlur(full-res, ksize, sigma) then the
@@ -248,105 +241,6 @@ __host__ __device__ constexpr int d16_pair_tiles(int w) { return (d16_nyb(w) * 5
 // second wave forms vsum(x+7) - vsum(x-8) and stores it (ds_bpermute would cost ~20 cycles per wave64 on
 // gfx950, an LDS write + two reads ~1/3 of that).
 // ---------------------------------------------------------------------------------------
-struct NeIn { float dx, dy, r0[5]; };
-struct NeG { float top[10], bot[10]; };            // (y1,x1..x1+1) and (y1+1,x1..x1+1), 5 coefficients each
-
-struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
-struct __attribute__((packed, aligned(4))) F2 { float a, b; };
-
-// R is interleaved [frame][y][x][5]; flow planar [pair][2][y][x].  Addressing is "uniform base + unsigned
-// 32-bit BYTE offset" (both buffers are smaller than 4 GiB), which the compiler turns into the
-// saddr + voffset form of global_load: no 64-bit address arithmetic per load.  Wide loads on 4-byte-aligned
-// addresses.
-template <typename T>
-__device__ __forceinline__ T ld_off(const void* __restrict__ base, unsigned byte_off)
-{
-    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
-}
-
-template <typename T>
-__device__ __forceinline__ void st_off(void* __restrict__ base, unsigned byte_off, T v)
-{
-    *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off) = v;
-}
-
-// non-temporal store: D is written once and read once by the next kernel.  Measured A/B on one box, 3 rounds
-// each, D stores and D loads non-temporal vs plain: k_hscan<320> 0.146 -> 0.121 ms, k_uv<320> 0.288 -> 0.300 ms,
-// 59.3 k -> 61.4 k frames/s with 3 clips in flight (loads alone: hscan 0.115 ms but 58.5 k frames/s; the same
-// treatment of the preprocess input loads LOST 4 %)
-template <typename T>
-__device__ __forceinline__ void st_off_nt(void* __restrict__ base, unsigned byte_off, T v)
-{
-    __builtin_nontemporal_store(v, reinterpret_cast<T*>(static_cast<char*>(base) + byte_off));
-}
-
-__device__ __forceinline__ void ne_load(const float* __restrict__ R, const float* __restrict__ flow, unsigned r0base,
-                                        unsigned flbase, int x, int y, int w, int plane, NeIn& in)
-{
-    const unsigned o = (unsigned)(y * w + x);
-    in.dx = ld_off<float>(flow, (flbase + o) * 4u); in.dy = ld_off<float>(flow, (flbase + plane + o) * 4u);
-    const unsigned pb = (r0base + o * 5u) * 4u;
-    const F4 v = ld_off<F4>(R, pb);
-    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off<float>(R, pb + 16u);
-}
-
-// gather the four bilinear neighbours of the warped position (clamped address when outside:
-// the values are discarded by ne_finish, exactly as cv2 takes the "else" branch there)
-__device__ __forceinline__ void ne_gather(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
-                                          int w, int h, int plane, NeG& g)
-{
-    const float fx = x + in.dx, fy = y + in.dy;
-    const int x1 = clampi(floor_f(fx), 0, w - 2), y1 = clampi(floor_f(fy), 0, h - 2);
-    const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
-    const F4 t0 = ld_off<F4>(R, pb), t1 = ld_off<F4>(R, pb + 16u);
-    const F2 t2 = ld_off<F2>(R, pb + 32u);
-    const F4 b0 = ld_off<F4>(R, qb), b1 = ld_off<F4>(R, qb + 16u);
-    const F2 b2 = ld_off<F2>(R, qb + 32u);
-    g.top[0] = t0.a; g.top[1] = t0.b; g.top[2] = t0.c; g.top[3] = t0.d; g.top[4] = t1.a;
-    g.top[5] = t1.b; g.top[6] = t1.c; g.top[7] = t1.d; g.top[8] = t2.a; g.top[9] = t2.b;
-    g.bot[0] = b0.a; g.bot[1] = b0.b; g.bot[2] = b0.c; g.bot[3] = b0.d; g.bot[4] = b1.a;
-    g.bot[5] = b1.b; g.bot[6] = b1.c; g.bot[7] = b1.d; g.bot[8] = b2.a; g.bot[9] = b2.b;
-}
-
-__device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, int y, int w, int h, float (&M)[5])
-{
-    // Branch-free on purpose (selects, multiplication by an exact 1.0f): a conditional block here lets the
-    // compiler sink the gathered loads into it, right in front of their use, and makes its vmcnt counts
-    // conservative at the join -- either way the software pipeline of k_uv / k_uvp collapses.
-    const float dx = in.dx, dy = in.dy;
-    float fx = x + dx, fy = y + dy;
-    const int x1 = floor_f(fx), y1 = floor_f(fy);
-    fx -= x1; fy -= y1;
-    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    const float b2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
-    const float b3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
-    const float b4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
-    const float b5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
-    const float b6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
-    float r2 = inside ? b2 : 0.f, r3 = inside ? b3 : 0.f;
-    float r4 = inside ? (in.r0[2] + b4) * 0.5f : in.r0[2];
-    float r5 = inside ? (in.r0[3] + b5) * 0.5f : in.r0[3];
-    float r6 = inside ? (in.r0[4] + b6) * 0.25f : in.r0[4] * 0.5f;
-    r2 = (in.r0[0] - r2) * 0.5f;
-    r3 = (in.r0[1] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    {
-        auto border = [](int d) { return d < 2 ? 0.14f : 0.4472f; };      // {.14,.14,.4472,.4472,.4472}
-        const bool edge = (unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10);
-        const float sc = (x < 5 ? border(x) : 1.f) * (x >= w - 5 ? border(w - x - 1) : 1.f) *
-                         (y < 5 ? border(y) : 1.f) * (y >= h - 5 ? border(h - y - 1) : 1.f);
-        const float scale = edge ? sc : 1.f;             // interior: x * 1.0f == x exactly
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    }
-    M[0] = r4 * r4 + r6 * r6;
-    M[1] = (r4 + r5) * r6;
-    M[2] = r5 * r5 + r6 * r6;
-    M[3] = r4 * r2 + r6 * r3;
-    M[4] = r6 * r2 + r5 * r3;
-}
-
 // ---------------------------------------------------------------------------------------
 // k_uvp: the same computation as a producer / consumer workgroup.  Per row of a strip, ~80 % of the
 // instructions (loads, bilinear gather, normal equations) do not depend on the previous row; only five
@@ -972,6 +866,14 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
             else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
             else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
+        }
+        // ctx->fb_fused (AVD_FB_FUSED / avd_set_option "fb_fused"): bit k set = level k runs the fused kernel (avd_fbfused.hip: all three iterations in one launch,
+        // D never leaves the chip); clear = the two-kernel path below
+        if ((ctx->fb_fused >> k) & 1) {
+            if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
+            if (int e = launch_fb_level(ctx, stream, w, g.poly[k], g.flow[k], np, 3)) return e;
+            if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
+            continue;
         }
         for (int it = 0; it < 3; it++) {
             switch (k) {

@@ -120,6 +120,7 @@ struct avd_ctx {
     FbConsts fbc;
     void* d_fbc = nullptr;          // FbConsts on device
     int last_n = 0;
+    int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
 };
 
 // ---- stage launchers (each enqueues on ctx->stream) --------------------------------
@@ -130,3 +131,5 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
 int launch_hash(avd_ctx* ctx, int n);
 int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off);
 int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);
+// avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
+int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations);

@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the per-frame video-analysis hot path on MI355X.
 
 A "step" = one pass of the hot path (fused preprocess -> aHash/Hamming -> Farneback -> flow
-statistics -> per-frame records -> scalar timeline tail) over ONE synthetic clip per GPU:
+statistics -> per-frame records -> scalar timeline tail -> fusion) over ONE synthetic clip per GPU:
 BASELINE.json configs[1], a 1080p30 60 s clip sampled at 2 fps = 120 BGR frames
 (uint8[120,1080,1920,3], 746 MB) already resident in HBM when the timed region starts.
 With N > 1 ranks every rank analyses its own clip (whole clips per GPU) and one
@@ -11,13 +11,28 @@ RCCL all-gather of the 32-byte per-frame records reassembles all timelines: weak
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-"roofline" (fused preprocess kernel vs HBM peak, timed with HIP events on the library's own
-stream) and "cpu_baseline" (the CPU oracle, kind "port", timed on this box's host cores).
+Prints ONE JSON line on rank 0.  What is measured, and how:
+  value / ms_per_step   W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks;
+                        the K-step region is repeated --repeats times in the same process and the MEDIAN repeat is
+                        reported (min / max beside it: boxes and DVFS move a single 25 ms region by several percent).
+                        --inflight clips are in flight per GPU, each on its own avd context AND its own copy of the
+                        input in HBM (a service never analyses the same buffer three times at once).
+  roofline              the kernel with the largest share of the step: the fused Farneback level kernel at 320x320
+                        (all iterations of the level in one launch), timed with HIP events around the launch on the
+                        library's own stream while clips run ALONE (an exclusive pass before the timed region; with
+                        clips in flight an event-to-event time includes whatever shares the GPU).  achieved =
+                        ALGORITHMIC bytes per launch / average launch duration; traffic = HBM bytes per launch from
+                        the committed rocprofv3 --pmc passes (profiles/).
+  roofline_preprocess   the HBM-bound fused full-resolution kernel (north_star's ">= 60 % of HBM peak" target).
+  config.sec_per_video  BASELINE.json's second metric: latency of one clip from decoded frames in PINNED HOST memory to
+                        the final result (PCIe-inclusive); the HBM-resident latency is beside it.
+  pcie_inclusive_fps    whole-job rate when every clip is handed over as a pinned host buffer (never `value`).
+  cpu_baseline          the CPU oracle (kind "port"), clip-parallel on the host cores, bounded sample.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,46 +45,71 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 FP32_VALU_PEAK_TF = 157.3
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")     # HBM bytes per launch from rocprofv3 --pmc passes
 
 
-def algorithmic_bytes_per_frame(h, w):
-    """one read of the BGR frame + the small outputs (320x320 gray, 1024 hash
-    bits, two int64 moments)."""
+def preprocess_bytes_per_frame(h, w):
+    """one read of the BGR frame + the small outputs (320x320 gray, 1024 hash bits, two int64 moments)."""
     return h * w * 3 + 320 * 320 + 1024 + 16
 
 
-def farneback_model(n_frames, stage_ms, uv_ms, hscan_ms, ms_per_step):
-    """The Farneback stage (all pairs of the clip, 4 pyramid scales, 3 iterations) and its two dominant
-    kernels at 320x320, timed live with HIP events around each launch (avd_stage_ms 4 / 5).
-    Algorithmic bytes per pixel and launch: k_uv reads R0 and R1 (5 floats each) and the
-    flow (2 floats) and writes D (5 doubles) = 88 B; k_hscan reads D and writes the flow = 48 B.
-    'traffic' = HBM bytes per launch from the committed PMC passes (profiles/r01_farneback_pmc.json).
-    Stage level: 'design_traffic' = 136 B per pixel and iteration over all four scales; flop count from the
-    operation list in DESIGN.md 4.3 (~73 Mflop per pair): far from the vector-FP32 roofline."""
-    pairs, px = max(n_frames - 1, 0), 320 * 320 + 160 * 160 + 80 * 80 + 40 * 40
-    pmc = {}
-    pmc_file = os.path.join(ROOT, "profiles", "r01_farneback_pmc.json")
-    if os.path.exists(pmc_file) and n_frames == 120:
-        with open(pmc_file) as fh:
-            pmc = json.load(fh).get("kernels", {})
+def fused_level_bytes(n_frames, iterations=3, w=320):
+    """Algorithmic bytes of ONE launch of the fused Farneback level kernel: per iteration every
+    frame's polynomial expansion is read once (5 floats per pixel; a frame is R0 of one pair and R1 of the next)
+    and every pair's flow is read and written once (2 floats each way).  The on-chip working set of a pair (4 MB of
+    R + 0.8 MB of flow) exceeds LDS, so each iteration streams it again."""
+    pairs = max(n_frames - 1, 0)
+    per_iter = n_frames * w * w * 20 + pairs * w * w * 16
+    return iterations * per_iter
 
-    def kernel(name, what, bytes_px, ms, launches):
-        alg = pairs * 320 * 320 * bytes_px
-        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": what, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc.get(name, {}).get("hbm_bytes"),
-                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(ms, 4), "launches_per_step": launches,
-                "share_of_step": round(launches * ms / ms_per_step, 4) if ms_per_step > 0 else 0.0}
 
-    traffic = pairs * px * 3 * 136
-    flops = pairs * 73e6
+def load_pmc():
+    if os.path.exists(PMC_FILE):
+        with open(PMC_FILE) as fh:
+            return json.load(fh)
+    return {}
+
+
+def roofline_objects(n, h, w, stage, latency_ms):
+    """stage: avd_stage_ms of clips run alone: [preprocess, hash.., farneback+stats, copy-out, fused level 0, -]."""
+    pmc = load_pmc() if (n, h, w) == (120, 1080, 1920) else {}
+    pairs = max(n - 1, 0)
+    fb_ms, pre_ms, stage_ms = float(stage[4]), float(stage[0]), float(stage[2])
+    alg = fused_level_bytes(n)
+    ach = alg / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0
+    flops = pairs * 73e6 * (320 * 320 * 3) / ((320 * 320 + 160 * 160 + 80 * 80 + 40 * 40) * 3)   # level-0 share of ~73 Mflop per pair
+    dominant = {
+        "kernel": "k_fb_level<320> (Farneback level 0: normal equations + vertical / horizontal double running sums + 2x2 solve, "
+                  "3 iterations in one launch, one workgroup per pair, D never leaves the chip)",
+        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        "traffic": pmc.get("k_fb_level<320>", {}).get("hbm_bytes"),
+        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(fb_ms, 4), "launches_per_step": 1,
+        "share_of_step": round(fb_ms / latency_ms, 4) if latency_ms > 0 else 0.0,
+        "bound_note": "measured (in-kernel stamps, profiles/r02_experiments.md): the kernel is bound by VALU issue of the "
+                      "exact normal equations and by the dependent double-add chain of the horizontal scan, not by HBM -- the "
+                      "fraction of HBM peak is low BY CONSTRUCTION: 80 of the 136 B per pixel and iteration of the two-kernel "
+                      "path (the double intermediate D) no longer exist",
+        "valu": {"flops": round(flops), "tflops": round(flops / (fb_ms * 1e-3) / 1e12, 2) if fb_ms > 0 else 0.0,
+                 "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF},
+        "timed": "HIP events around the launch on the library's stream, clips run alone before the timed region",
+    }
+    alg_pre = preprocess_bytes_per_frame(h, w) * n
+    ach_pre = alg_pre / (pre_ms * 1e-3) / 1e9 if pre_ms > 0 else 0.0
+    pre = {"kernel": "k_preprocess_vec (fused BGR->gray, INTER_AREA partials, INTER_LINEAR 320x320, Laplacian moments)",
+           "bound": "hbm", "achieved": round(ach_pre, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach_pre / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_preprocess_vec", {}).get("hbm_bytes"),
+           "algorithmic_bytes_per_launch": alg_pre, "avg_launch_ms": round(pre_ms, 4),
+           "share_of_step": round(pre_ms / latency_ms, 4) if latency_ms > 0 else 0.0}
+    px = 320 * 320 + 160 * 160 + 80 * 80 + 40 * 40
+    fb_alg = sum(fused_level_bytes(n, 3, ww) for ww in (320, 160, 80, 40))
     t = stage_ms * 1e-3
-    return {"stage": "Farneback + flow statistics", "avg_ms": round(stage_ms, 4), "bound": "hbm",
-            "k_uv_320": kernel("k_uv<320>", "k_uv<320> (normal equations fused with the vertical double running sums)", 88, uv_ms, 3),
-            "k_hscan_320": kernel("k_hscan<320>", "k_hscan<320> (horizontal double running sums + 2x2 solve)", 48, hscan_ms, 3),
-            "design_traffic_bytes": traffic, "achieved": round(traffic / t / 1e9, 1) if t > 0 else 0.0,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
-            "flops": flops, "tflops": round(flops / t / 1e12, 2) if t > 0 else 0.0, "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF}
+    fb = {"stage": "Farneback (pyramid, polynomial expansion, 4 fused level kernels) + flow statistics", "avg_ms": round(stage_ms, 4),
+          "algorithmic_bytes": fb_alg, "achieved": round(fb_alg / t / 1e9, 1) if t > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(fb_alg / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
+          "flops": pairs * 73e6, "tflops": round(pairs * 73e6 / t / 1e12, 2) if t > 0 else 0.0,
+          "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF, "pixels_per_pair_all_levels": px,
+          "traffic": pmc.get("farneback_stage", {}).get("hbm_bytes")}
+    return dominant, pre, fb
 
 
 _CPU_CHILD = r"""
@@ -91,7 +131,8 @@ def cpu_baseline(clip, meta, max_frames, procs):
     timed on a bounded sample of the same clip: (a) one thread, one clip -- the reference's per-request path;
     (b) `procs` independent processes, one clip each, which is how a CPU box would be loaded for throughput
     (clip-parallel, no GPU touched: fresh interpreters that only import numpy and the oracle)."""
-    import subprocess, tempfile
+    import subprocess
+    import tempfile
     from oracle import oracle as O
     O.lib()
     sample = np.ascontiguousarray(clip[:max_frames])
@@ -128,6 +169,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=25, help="the K-step timed region is repeated this many times in-process; "
+                                                            "the median repeat is reported (1 = a single region)")
     ap.add_argument("--frames", type=int, default=120, help="sampled frames per clip (120 = 60 s at 2 fps)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -135,13 +178,14 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=16,
                     help="processes of the clip-parallel CPU baseline (capped at the host's cores; 1 = single thread only)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) path, reported apart")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
+    ap.add_argument("--pcie", action="store_true", help="accepted for compatibility (the PCIe-inclusive figures are on by default)")
     ap.add_argument("--inflight", type=int, default=3,
-                    help="clips in flight per GPU, each on its own avd context / stream / workspace.  3 (default) = how a "
-                         "service drives the GPU: the next clips are submitted before the previous one is drained, so the "
-                         "latency-bound coarse pyramid levels, the records all-gather, the host tail and the launch gaps of "
-                         "one clip hide behind the bandwidth-bound kernels of another; 1 = every step is submitted and "
-                         "drained alone.  All K steps complete inside the timed region either way.")
+                    help="clips in flight per GPU, each on its own avd context / stream / workspace / input copy.  3 (default) = "
+                         "how a service drives the GPU: the next clips are submitted before the previous one is drained, so the "
+                         "per-pair workgroups of one clip's Farneback levels (119 of 256 CUs), the records all-gather, the host "
+                         "tail and the launch gaps of one clip overlap with the kernels of another; 1 = every step is submitted "
+                         "and drained alone.  All K steps complete inside the timed region either way.")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
@@ -149,9 +193,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     import avd_hip
     from avd_hip import synth, dist as avd_dist
@@ -184,24 +227,24 @@ def main():
     n, h, w = args.frames, args.height, args.width
     meta = {"width": w, "height": h, "fps": 30.0, "duration": n / 2.0}
     clip = synth.make_clip(n, h, w, seed=args.seed + rank)          # synthetic, SURVEY.md 8(d) recipe
-    frames = torch.from_numpy(clip).to(dev)                          # resident in HBM before timing
     m = max(1, args.inflight)
+    host = torch.from_numpy(clip)
+    frames = [host.to(dev) for _ in range(m)]                        # one resident copy per in-flight slot
     ctxs = [avd_hip.Context(dev_index) for _ in range(m)]
     for c in ctxs:
         c.set_profiling(True)
-    ctx = ctxs[0]
     recs = [np.zeros(n, avd_hip.RECORD_DTYPE) for _ in range(m)]
     hints = heuristics_v2.compute_hints({**meta, "bit_rate": 8_000_000}, "")
     stage = np.zeros(6)
     pending = []
 
-    def submit(i):
+    def submit(i, src=None):
         j = i % m
-        ctxs[j].analyze_frames_async(frames, recs[j])
-        pending.append(j)
+        keep = ctxs[j].analyze_frames_async(frames[j] if src is None else src, recs[j])
+        pending.append((j, keep))
 
     def retire():
-        j = pending.pop(0)
+        j, _keep = pending.pop(0)
         ctxs[j].synchronize()
         stage[:] += np.array(ctxs[j].stage_ms())
         rec = recs[j]
@@ -211,12 +254,12 @@ def main():
         fused = fusion.fuse(audio_unavailable("", meta), video, hints)
         return video, fused
 
-    def run(steps):
+    def run(steps, src=None):
         out = None
         for i in range(steps):
             if len(pending) == m:
                 out = retire()
-            submit(i)
+            submit(i, src)
         while pending:
             out = retire()
         return out
@@ -226,10 +269,9 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    # EXCLUSIVE pass, before the timed region: clips submitted and drained alone.  It gives (a) the latency of
-    # one clip (BASELINE.json's second metric, sec per video) and (b) per-kernel durations from HIP events on the
-    # kernels' own stream that are not mixed with another clip's kernels -- with several clips in flight a kernel's
-    # event-to-event time includes whatever shares the GPU with it, which says nothing about the kernel.
+    # EXCLUSIVE pass, before the timed region: clips submitted and drained alone.  It gives (a) the resident latency of
+    # one clip and (b) per-kernel durations from HIP events on the kernels' own stream that are not mixed with another
+    # clip's kernels.
     for _ in range(args.warmup):
         submit(0)
         retire()
@@ -243,87 +285,90 @@ def main():
         lat.append(time.perf_counter() - t1)
         excl += stage
     excl /= n_excl
-    run(args.warmup)                  # W untimed warmup steps in the timed region's own (pipelined) mode
-    latency_ms = sorted(lat)[len(lat) // 2] * 1e3
-    stage[:] = 0
-    barrier()
-    t0 = time.perf_counter()
-    result, fused = run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stage /= max(args.steps, 1)
-    timed_region_stage = stage.copy()
-    if m > 1:
-        stage = excl                  # per-kernel numbers below come from the exclusive pass (see above)
+    latency_ms = statistics.median(lat) * 1e3
+
+    # decoded frames in PINNED HOST memory -> result: BASELINE.json's "end-to-end sec/video" (decode excluded)
+    host_lat_ms = pcie_fps = pcie_fps_inflight = None
+    if not args.no_pcie:
+        pinned = host.pin_memory()
+        submit(0, pinned)
+        retire()
+        hl = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            submit(0, pinned)
+            retire()
+            hl.append(time.perf_counter() - t1)
+        host_lat_ms = statistics.median(hl) * 1e3
+        pcie_fps = n / statistics.median(hl)
+        if m > 1:
+            reps = 4 * m
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(reps, pinned)
+            pcie_fps_inflight = reps * n / (time.perf_counter() - t1)
+
+    run(args.warmup)                  # W untimed warm-up steps in the timed region's own (pipelined) mode
+    elapsed_all, timed_stage = [], np.zeros(6)
+    result = fused = None
+    for _ in range(max(1, args.repeats)):
+        stage[:] = 0
+        barrier()
+        t0 = time.perf_counter()
+        result, fused = run(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        elapsed_all.append(elapsed)
+        timed_stage += stage / max(args.steps, 1)
+    timed_stage /= len(elapsed_all)
+    elapsed = statistics.median(elapsed_all)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        fps_total = world * n * args.steps / elapsed
-        pre_ms = float(stage[0])
-        alg = algorithmic_bytes_per_frame(h, w) * n
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this kernel
-        pmc_file = os.path.join(ROOT, "profiles", "r01_preprocess_pmc.json")
-        if os.path.exists(pmc_file) and (n, h, w) == (120, 1080, 1920):
-            with open(pmc_file) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
-        achieved = alg / (pre_ms * 1e-3) / 1e9 if pre_ms > 0 else 0.0
+        fps = lambda e: world * n * args.steps / e          # noqa: E731
+        dominant, pre, fb = roofline_objects(n, h, w, excl, latency_ms)
         out = {
             "metric": "sampled frames/sec analysed (1080p30 60 s clip, 2 fps sampling)",
-            "value": round(fps_total, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(fps(elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels; f32/f64 Farneback (cv2's own types)",
             "data": "synthetic",
+            "repeats": {"n": len(elapsed_all), "statistic": "median", "value_min": round(fps(max(elapsed_all)), 2),
+                        "value_max": round(fps(min(elapsed_all)), 2),
+                        "ms_per_step_min": round(min(elapsed_all) / args.steps * 1e3, 4),
+                        "ms_per_step_max": round(max(elapsed_all) / args.steps * 1e3, 4)},
             "config": {"workload": "BASELINE.json configs[1]: 1080p30 60 s clip, 2 fps sampling, one clip per GPU per step",
                        "frames_per_clip": n, "height": h, "width": w, "clips_per_step": world, "clips_in_flight_per_gpu": m,
-                       "sec_per_video": round(latency_ms / 1e3, 6),
-                       "sec_per_video_note": f"latency of one clip submitted and drained alone (median of {n_excl}, before the timed region)",
-                       "decoded_frame_equivalent_fps": round(fps_total * 15, 1),
+                       "input_copies_in_hbm": m,
+                       "sec_per_video": round((host_lat_ms if host_lat_ms is not None else latency_ms) / 1e3, 6),
+                       "sec_per_video_note": ("one clip alone, from decoded frames in pinned host memory to the fused result "
+                                              "(PCIe-inclusive, median of 5)" if host_lat_ms is not None else
+                                              "one clip alone, frames resident in HBM (--no-pcie)"),
+                       "sec_per_video_resident": round(latency_ms / 1e3, 6),
+                       "sec_per_video_resident_note": f"one clip alone, frames already in HBM (median of {n_excl}, before the timed region)",
+                       "decoded_frame_equivalent_fps": round(fps(elapsed) * 15, 1),
                        "parallelism": f"clip-parallel x{world}, one all-gather ({args.backend}) of 32 B/frame records" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_preprocess (fused BGR->gray, INTER_AREA partials, INTER_LINEAR 320x320, Laplacian moments)",
-                         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(pre_ms, 4),
-                         "share_of_step": round(pre_ms / latency_ms, 4),
-                         "timed": "HIP events on the kernel's stream, timed region" if m == 1 else
-                                  f"HIP events on the kernel's stream, {n_excl} clips run alone before the timed region "
-                                  "(in the timed region several clips share the GPU: see stages_ms_timed_region)"},
-            "roofline_farneback": farneback_model(n, float(stage[2]), float(stage[4]), float(stage[5]), latency_ms),
-            "stages_ms": {"preprocess": round(float(stage[0]), 4), "hash_hamming_records": round(float(stage[1]), 4),
-                          "farneback_and_flow_stats": round(float(stage[2]), 4), "records_copy_out": round(float(stage[3]), 4)},
-            "stages_ms_timed_region": {"preprocess": round(float(timed_region_stage[0]), 4),
-                                       "farneback_and_flow_stats": round(float(timed_region_stage[2]), 4),
-                                       "k_uv_320": round(float(timed_region_stage[4]), 4),
-                                       "k_hscan_320": round(float(timed_region_stage[5]), 4),
+            "roofline": dominant,
+            "roofline_preprocess": pre,
+            "roofline_farneback_stage": fb,
+            "stages_ms": {"preprocess": round(float(excl[0]), 4), "hash_hamming_records": round(float(excl[1]), 4),
+                          "farneback_and_flow_stats": round(float(excl[2]), 4), "records_copy_out": round(float(excl[3]), 4),
+                          "fused_level0": round(float(excl[4]), 4),
+                          "note": "HIP events on the library's stream, clips run alone before the timed region"},
+            "stages_ms_timed_region": {"preprocess": round(float(timed_stage[0]), 4),
+                                       "farneback_and_flow_stats": round(float(timed_stage[2]), 4),
+                                       "fused_level0": round(float(timed_stage[4]), 4),
                                        "note": "event-to-event times while other clips share the GPU"},
             "result_check": {"ai_timeline_head": [round(v, 6) for v in result["timeline"][:3]],
                              "dup_density": result["summary"]["dup_density"], **fused["result"]},
         }
-        if args.pcie and world == 1:
-            # boundary handing over HOST buffers: pinned host frames staged by hipMemcpyAsync inside the call;
-            # (a) one clip at a time, (b) `m` clips in flight so that a clip's host-to-device copy overlaps the
-            # kernels of the others (the 63 GB/s link bounds this at ~10 k 1080p frames/s)
-            host = torch.from_numpy(clip).pin_memory()
-            ctx.analyze_frames(host)
-            t1 = time.perf_counter()
-            for _ in range(3):
-                ctx.analyze_frames(host)
-            out["pcie_inclusive_fps"] = round(3 * n / (time.perf_counter() - t1), 1)
-            if m > 1:
-                reps = 4 * m
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(reps):
-                    if len(pending) == m:
-                        retire()
-                    ctxs[i % m].analyze_frames_async(host, recs[i % m])
-                    pending.append(i % m)
-                while pending:
-                    retire()
-                out["pcie_inclusive_fps_in_flight"] = round(reps * n / (time.perf_counter() - t1), 1)
+        if pcie_fps is not None:
+            out["pcie_inclusive_fps"] = round(pcie_fps_inflight if pcie_fps_inflight is not None else pcie_fps, 1)
+            out["pcie_inclusive_fps_one_clip_at_a_time"] = round(pcie_fps, 1)
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(clip, meta, min(args.cpu_frames, n), max(1, min(args.cpu_procs, os.cpu_count() or 1)))
         else:

@@ -124,10 +124,15 @@ int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
 /* Per-stage device time (ms, HIP events on ctx's stream) of the LAST avd_analyze_frames*
  * call when profiling was enabled with avd_set_profiling(ctx, 1): stage 0 = fused
  * preprocess kernel (+ the 2 KB moment memset), 1 = hash / Hamming / record kernels,
- * 2 = Farneback (pyramid .. flow) + flow statistics, 3 = records copy-out; 4 / 5 = mean duration of
- * ONE launch of the two dominant Farneback kernels at 320x320 (vertical-sum kernel k_uv / horizontal
- * scan k_hscan; three launches each per call, events around each launch). */
+ * 2 = Farneback (pyramid .. flow) + flow statistics, 3 = records copy-out; 4 = duration of the fused level kernel at
+ * 320x320 (all iterations of pyramid level 0 in one launch, events around the launch; with the two-kernel path selected
+ * by AVD_FB_FUSED: mean duration of one k_uv launch), 5 = mean duration of one k_hscan<320> launch (two-kernel path only,
+ * otherwise 0). */
 int avd_set_profiling(avd_ctx* ctx, int enable);
+/* Tuning / test switches (no effect on results).  "fb_fused": bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
+ * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
+ * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM. */
+int avd_set_option(avd_ctx* ctx, const char* name, int value);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 
 /* Test hook: copy an internal device buffer of the last call to host.

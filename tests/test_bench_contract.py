@@ -21,29 +21,35 @@ def _bench():
 
 def test_algorithmic_bytes_match_the_survey():
     b = _bench()
-    assert b.algorithmic_bytes_per_frame(1080, 1920) == 6_324_240
-    assert b.algorithmic_bytes_per_frame(720, 1280) == 2_868_240
-    assert b.algorithmic_bytes_per_frame(2160, 3840) == 24_986_640
+    assert b.preprocess_bytes_per_frame(1080, 1920) == 6_324_240
+    assert b.preprocess_bytes_per_frame(720, 1280) == 2_868_240
+    assert b.preprocess_bytes_per_frame(2160, 3840) == 24_986_640
 
 
-def test_farneback_kernel_roofline_objects():
+def test_roofline_objects():
+    """The dominant kernel (fused Farneback level 0) is `roofline`; its algorithmic bytes count every frame's
+    polynomial expansion ONCE per iteration (a frame is R0 of one pair and R1 of the next) plus the flow read and
+    written once -- never more than the kernel can have moved."""
     b = _bench()
-    m = b.farneback_model(120, stage_ms=2.26, uv_ms=0.30, hscan_ms=0.14, ms_per_step=2.6)
-    uv, hs = m["k_uv_320"], m["k_hscan_320"]
-    assert uv["algorithmic_bytes_per_launch"] == 119 * 320 * 320 * 88       # R0 20 + R1 20 + flow 8 read, D 40 written
-    assert hs["algorithmic_bytes_per_launch"] == 119 * 320 * 320 * 48       # D 40 read, flow 8 written
-    for k in (uv, hs):
+    per_iter = 120 * 320 * 320 * 20 + 119 * 320 * 320 * 16
+    assert b.fused_level_bytes(120) == 3 * per_iter
+    assert per_iter < 119 * 320 * 320 * (20 + 20 + 8 + 8)              # R once per FRAME, not once per pair
+    stage = [0.158, 0.027, 1.9, 0.006, 1.0, 0.0]
+    dom, pre, fb = b.roofline_objects(120, 1080, 1920, stage, latency_ms=2.2)
+    for k in (dom, pre):
         assert k["bound"] == "hbm" and k["unit"] == "GB/s" and k["peak"] == 8000.0
         assert abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-3
-        assert k["launches_per_step"] == 3
-    assert abs(uv["achieved"] - uv["algorithmic_bytes_per_launch"] / 0.30e-3 / 1e9) < 1.0
-    assert m["design_traffic_bytes"] == 119 * (320 * 320 + 160 * 160 + 80 * 80 + 40 * 40) * 3 * 136
+        assert k["traffic"] is None or k["traffic"] >= 0.9 * k["algorithmic_bytes_per_launch"]   # algorithmic <= measured
+    assert abs(dom["achieved"] - 3 * per_iter / 1.0e-3 / 1e9) < 1.0 and dom["launches_per_step"] == 1
+    assert abs(pre["achieved"] - 120 * 6_324_240 / 0.158e-3 / 1e9) < 1.0
+    assert "k_fb_level<320>" in dom["kernel"] and 0 < dom["share_of_step"] < 1
+    assert fb["algorithmic_bytes"] == sum(b.fused_level_bytes(120, 3, w) for w in (320, 160, 80, 40))
 
 
 def test_cli_defaults_are_the_driver_contract():
     import re
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for flag, default in (("--gpus", "1"), ("--steps", "20"), ("--warmup", "3"), ("--inflight", "3")):
+    for flag, default in (("--gpus", "1"), ("--steps", "20"), ("--warmup", "3"), ("--inflight", "3"), ("--repeats", "25")):
         assert re.search(r'add_argument\("%s", type=int, default=%s' % (re.escape(flag), default), src), flag
     # one JSON line on stdout, printed by rank 0 only
     assert src.count("print(json.dumps(out))") == 1

@@ -134,6 +134,22 @@ def test_farneback_hard_inputs_bit_exact(ctx, oracle):
     assert np.isfinite(flow).all()
 
 
+def test_fused_and_two_kernel_paths_agree(oracle):
+    """Every pyramid level can run the fused kernel (default) or the k_uv / k_uvp + k_hscan pair that exchanges the
+    double intermediate through HBM: all 16 combinations give the oracle's flow, bit for bit."""
+    import avd_hip
+    small = _smalls(oracle, 3, seed=14)
+    want = [oracle.farneback(small[p], small[p + 1]) for p in range(2)]
+    with avd_hip.Context(0) as c:
+        for mask in (0xF, 0x0, 0x1, 0x2, 0x4, 0x8, 0x5, 0xA, 0xE):
+            c.set_option("fb_fused", mask)
+            fm, fv, flow = c.farneback_pairs(small, want_flow=True)
+            for p in range(2):
+                assert np.array_equal(flow[p], want[p]), (hex(mask), p)
+        with pytest.raises(avd_hip.AvdError):
+            c.set_option("no_such_option", 1)
+
+
 def test_flow_stats_match_numpy(ctx, oracle):
     small = _smalls(oracle, 4, seed=12)
     fm, fv, flow = ctx.farneback_pairs(small, want_flow=True)
