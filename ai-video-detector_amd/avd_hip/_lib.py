@@ -24,6 +24,7 @@ EXPORTS = (
     "avd_abi_version", "avd_create", "avd_destroy", "avd_last_error",
     "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
     "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
+    "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
@@ -90,6 +91,10 @@ def load() -> C.CDLL:
     L.avd_farneback_pairs.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, f32p, f32p]
     L.avd_analyze_frames.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp]
     L.avd_analyze_frames_async.argtypes = L.avd_analyze_frames.argtypes
+    nv12 = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+    L.avd_preprocess_nv12.argtypes = nv12 + [u8p, u8p, i64p, i64p]
+    L.avd_analyze_frames_nv12.argtypes = nv12 + [vp]
+    L.avd_analyze_frames_nv12_async.argtypes = nv12 + [vp]
     L.avd_synchronize.argtypes = [vp]
     L.avd_wait_stream.argtypes = [vp, vp]
     L.avd_release_workspace.argtypes = [vp]
@@ -212,6 +217,56 @@ class Context:
         rec = np.zeros(n, RECORD_DTYPE)
         self._check(self._L.avd_analyze_frames(self._h, ptr, mem, n, h, w, rs, fs, rec.ctypes.data))
         return rec
+
+    # -- NV12 (decoder surfaces): y uint8[N,H,W], uv uint8[N,H/2,W] with U,V interleaved ----------------------
+    def _nv12_ptrs(self, y, uv):
+        """-> (yptr, uvptr, mem, n, h, w, y_row, uv_row, y_frame, uv_frame, keepalive)"""
+        if _is_torch_tensor(y) != _is_torch_tensor(uv):
+            raise ValueError("both planes must be numpy arrays or both torch tensors")
+        if _is_torch_tensor(y):
+            if y.dim() != 3 or uv.dim() != 3 or str(y.dtype) != "torch.uint8" or str(uv.dtype) != "torch.uint8" or y.is_cuda != uv.is_cuda:
+                raise ValueError("planes must be uint8[N,H,W] and uint8[N,H/2,W] on the same device")
+            ok = lambda t: t.stride(2) == 1 and t.stride(1) >= t.shape[2] and (t.shape[0] == 1 or t.stride(0) >= t.stride(1) * t.shape[1])
+            y, uv = (y if ok(y) else y.contiguous()), (uv if ok(uv) else uv.contiguous())
+            if y.is_cuda:
+                self._after_torch_stream(y)
+            n, h, w = y.shape
+            strides = (y.stride(1), uv.stride(1), y.stride(0) if n > 1 else h * y.stride(1), uv.stride(0) if n > 1 else (h // 2) * uv.stride(1))
+            ptrs, mem = (y.data_ptr(), uv.data_ptr()), (AVD_MEM_DEVICE if y.is_cuda else AVD_MEM_HOST)
+        else:
+            y, uv = np.asarray(y), np.asarray(uv)
+            if y.ndim != 3 or uv.ndim != 3 or y.dtype != np.uint8 or uv.dtype != np.uint8:
+                raise ValueError("planes must be uint8[N,H,W] and uint8[N,H/2,W]")
+            ok = lambda a: a.strides[2] == 1 and a.strides[1] >= a.shape[2] and (a.shape[0] == 1 or a.strides[0] >= a.strides[1] * a.shape[1])
+            y, uv = (y if ok(y) else np.ascontiguousarray(y)), (uv if ok(uv) else np.ascontiguousarray(uv))
+            n, h, w = y.shape
+            strides = (y.strides[1], uv.strides[1], y.strides[0] if n > 1 else h * y.strides[1], uv.strides[0] if n > 1 else (h // 2) * uv.strides[1])
+            ptrs, mem = (y.ctypes.data, uv.ctypes.data), AVD_MEM_HOST
+        if tuple(uv.shape) != (n, h // 2, w):
+            raise ValueError(f"chroma plane must be uint8[{n},{h // 2},{w}] (interleaved U,V), got {tuple(uv.shape)}")
+        return ptrs + (mem, n, h, w) + strides + ((y, uv),)
+
+    def preprocess_nv12(self, y, uv):
+        yp, cp, mem, n, h, w, yr, cr, yf, cf, keep = self._nv12_ptrs(y, uv)
+        small = np.empty((n, SMALL, SMALL), np.uint8)
+        hsh = np.empty((n, HASH * HASH), np.uint8)
+        s = np.empty(n, np.int64)
+        q = np.empty(n, np.int64)
+        self._check(self._L.avd_preprocess_nv12(self._h, yp, cp, mem, n, h, w, yr, cr, yf, cf, small.ctypes.data,
+                                                hsh.ctypes.data, s.ctypes.data, q.ctypes.data))
+        return small, hsh, s, q
+
+    def analyze_frames_nv12(self, y, uv) -> np.ndarray:
+        yp, cp, mem, n, h, w, yr, cr, yf, cf, keep = self._nv12_ptrs(y, uv)
+        rec = np.zeros(n, RECORD_DTYPE)
+        self._check(self._L.avd_analyze_frames_nv12(self._h, yp, cp, mem, n, h, w, yr, cr, yf, cf, rec.ctypes.data))
+        return rec
+
+    def analyze_frames_nv12_async(self, y, uv, rec: np.ndarray):
+        yp, cp, mem, n, h, w, yr, cr, yf, cf, keep = self._nv12_ptrs(y, uv)
+        assert rec.dtype == RECORD_DTYPE and rec.size >= n and rec.flags.c_contiguous
+        self._check(self._L.avd_analyze_frames_nv12_async(self._h, yp, cp, mem, n, h, w, yr, cr, yf, cf, rec.ctypes.data))
+        return keep
 
     def analyze_frames_async(self, frames, rec: np.ndarray):
         ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)

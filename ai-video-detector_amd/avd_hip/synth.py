@@ -50,3 +50,21 @@ def make_clip(n: int, h: int, w: int, seed: int = 0, dup_every: int = 10, scene_
 def random_frames(n: int, h: int, w: int, seed: int = 0) -> np.ndarray:
     """White-noise frames: worst case for every integer path (all byte values, no smoothness)."""
     return np.random.default_rng(seed).integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+
+
+def bgr_to_nv12(frames: np.ndarray):
+    """Synthetic decoder surfaces for the NV12 ingest path: BT.601 limited-range Y plane uint8[n,h,w] and an
+    interleaved U,V plane uint8[n,h/2,w] (2x2 chroma average) of BGR frames uint8[n,h,w,3] (h, w even).
+    This is only a data generator (a forward transform in float); the inverse the product implements is
+    libswscale's integer conversion."""
+    f = frames.astype(np.float32)
+    b, g, r = f[..., 0], f[..., 1], f[..., 2]
+    y = 16.0 + (65.481 * r + 128.553 * g + 24.966 * b) / 255.0
+    u = 128.0 + (-37.797 * r - 74.203 * g + 112.0 * b) / 255.0
+    v = 128.0 + (112.0 * r - 93.786 * g - 18.214 * b) / 255.0
+    n, h, w = y.shape
+    sub = lambda c: c.reshape(n, h // 2, 2, w // 2, 2).mean(axis=(2, 4))
+    uv = np.empty((n, h // 2, w), np.uint8)
+    uv[..., 0::2] = np.clip(np.rint(sub(u)), 0, 255).astype(np.uint8)
+    uv[..., 1::2] = np.clip(np.rint(sub(v)), 0, 255).astype(np.uint8)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8), uv

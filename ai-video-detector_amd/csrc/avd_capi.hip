@@ -357,24 +357,18 @@ static int impl_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, 
     return AVD_OK;
 }
 
-static int impl_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
-                             int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
+// Everything after the input-specific first stage: `first_stage` stages the input (if it lives on the host) and
+// enqueues the fused full-resolution kernel for its pixel format.
+template <typename F>
+static int analyze_async_common(avd_ctx* ctx, int n, int h, int w, avd_frame_record* records, F&& first_stage)
 {
-    if (!ctx) return AVD_ERR_ARG;
-    if ((!bgr || !records) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
-    if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
     if (n == 0) return AVD_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pending_out) { if (int e = impl_synchronize(ctx)) return e; }     // a previous call was never drained
     if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
     if (int e = avd_ws_reserve_fb(ctx, n)) return e;
-    const uint8_t* d_bgr = nullptr;
-    const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
-    if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
     Workspace& ws = ctx->ws;
-    stage_mark(ctx, 0);
-    if (int e = launch_preprocess(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
-    stage_mark(ctx, 1);
+    if (int e = first_stage()) return e;            // marks stages 0 / 1 around its kernel
     if (int e = launch_hash(ctx, n)) return e;
     hipLaunchKernelGGL(k_records, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats, 0,
@@ -387,6 +381,105 @@ static int impl_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, 
     HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pending_out = records; ctx->pending_n = n;
     stage_mark(ctx, 4);
+    ctx->last_n = n;
+    return AVD_OK;
+}
+
+static int impl_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                             int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if ((!bgr || !records) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
+    return analyze_async_common(ctx, n, h, w, records, [&]() -> int {
+        const uint8_t* d_bgr = nullptr;
+        const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
+        if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
+        stage_mark(ctx, 0);
+        if (int e = launch_preprocess(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
+        stage_mark(ctx, 1);
+        return 0;
+    });
+}
+
+// ---- NV12 input (decoder surfaces) -------------------------------------------------------------------------
+struct Nv12Arg {
+    const uint8_t *y, *uv;
+    int64_t y_row, uv_row, y_frame, uv_frame;
+};
+
+static int check_nv12(avd_ctx* ctx, const Nv12Arg& a, int n, int h, int w)
+{
+    if (n < 0 || h <= 0 || w <= 0 || h > 16384 || w > 16384) { ctx->err = "bad frame geometry"; return AVD_ERR_ARG; }
+    if ((h | w) & 1) { ctx->err = "NV12 needs even width and height"; return AVD_ERR_UNSUPPORTED; }
+    if (h < AVD_HASH || w < AVD_HASH) { ctx->err = "frame smaller than 32x32: INTER_AREA upscaling is not on the path"; return AVD_ERR_UNSUPPORTED; }
+    if ((!a.y || !a.uv) && n > 0) { ctx->err = "null plane pointer"; return AVD_ERR_ARG; }
+    if (a.y_row < w || a.uv_row < w || (n > 1 && (a.y_frame < a.y_row * (h - 1) + w || a.uv_frame < a.uv_row * (h / 2 - 1) + w))) {
+        ctx->err = "strides smaller than the planes"; return AVD_ERR_ARG;
+    }
+    return 0;
+}
+
+// host planes are staged back to back (the chroma plane on a 256-byte boundary); device planes are used in place
+static int stage_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w, const uint8_t** d_y, Nv12Params* nv)
+{
+    nv->uv_row_stride = a.uv_row; nv->uv_frame_stride = a.uv_frame;
+    build_yuv_consts(nv->k);
+    if (mem == AVD_MEM_DEVICE) { *d_y = a.y; nv->uv = a.uv; return 0; }
+    if (mem != AVD_MEM_HOST) { ctx->err = "mem must be AVD_MEM_HOST or AVD_MEM_DEVICE"; return AVD_ERR_ARG; }
+    const size_t ybytes = (size_t)a.y_frame * (n - 1) + (size_t)a.y_row * (h - 1) + (size_t)w;
+    const size_t cbytes = (size_t)a.uv_frame * (n - 1) + (size_t)a.uv_row * (h / 2 - 1) + (size_t)w;
+    const size_t coff = (ybytes + 255) / 256 * 256;
+    Workspace& ws = ctx->ws;
+    if (ws.stage_bytes < coff + cbytes) {
+        if (int e = dev_alloc(ctx, ws.d_stage, coff + cbytes)) return e;
+        ws.stage_bytes = coff + cbytes;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_stage, a.y, ybytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_stage + coff, a.uv, cbytes, hipMemcpyHostToDevice, ctx->stream));
+    *d_y = ws.d_stage; nv->uv = ws.d_stage + coff;
+    return 0;
+}
+
+static int impl_analyze_frames_nv12_async(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w, avd_frame_record* records)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (!records && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    if (int e = check_nv12(ctx, a, n, h, w)) return e;
+    return analyze_async_common(ctx, n, h, w, records, [&]() -> int {
+        const uint8_t* d_y = nullptr;
+        Nv12Params nv{};
+        if (int e = stage_nv12(ctx, a, mem, n, h, w, &d_y, &nv)) return e;
+        stage_mark(ctx, 0);
+        if (int e = launch_preprocess_nv12(ctx, d_y, nv, n, h, w, a.y_row, a.y_frame)) return e;
+        stage_mark(ctx, 1);
+        return 0;
+    });
+}
+
+static int impl_preprocess_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w,
+                                uint8_t* small320, uint8_t* hash1024, int64_t* lap_sum, int64_t* lap_sumsq)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (int e = check_nv12(ctx, a, n, h, w)) return e;
+    if (n == 0) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
+    const uint8_t* d_y = nullptr;
+    Nv12Params nv{};
+    if (int e = stage_nv12(ctx, a, mem, n, h, w, &d_y, &nv)) return e;
+    if (int e = launch_preprocess_nv12(ctx, d_y, nv, n, h, w, a.y_row, a.y_frame)) return e;
+    if (int e = launch_hash(ctx, n)) return e;
+    Workspace& ws = ctx->ws;
+    std::vector<unsigned long long> lap((size_t)n * 2);
+    if (small320) HIP_TRY(ctx, hipMemcpyAsync(small320, ws.d_small, (size_t)n * AVD_NPIX, hipMemcpyDeviceToHost, ctx->stream));
+    if (hash1024) HIP_TRY(ctx, hipMemcpyAsync(hash1024, ws.d_hash, (size_t)n * 1024, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lap.data(), ws.d_lap, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++) {
+        if (lap_sum) lap_sum[f] = (int64_t)lap[2 * f];
+        if (lap_sumsq) lap_sumsq[f] = (int64_t)lap[2 * f + 1];
+    }
     ctx->last_n = n;
     return AVD_OK;
 }
@@ -567,6 +660,33 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
 }
 
 int avd_synchronize(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_synchronize(ctx); }); }
+
+int avd_preprocess_nv12(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w, int64_t y_row_stride,
+                        int64_t uv_row_stride, int64_t y_frame_stride, int64_t uv_frame_stride, uint8_t* small320,
+                        uint8_t* hash1024, int64_t* lap_sum, int64_t* lap_sumsq)
+{
+    const Nv12Arg a{y, uv, y_row_stride, uv_row_stride, y_frame_stride, uv_frame_stride};
+    return guarded(ctx, [&] { return impl_preprocess_nv12(ctx, a, mem, n, h, w, small320, hash1024, lap_sum, lap_sumsq); });
+}
+
+int avd_analyze_frames_nv12_async(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w,
+                                  int64_t y_row_stride, int64_t uv_row_stride, int64_t y_frame_stride,
+                                  int64_t uv_frame_stride, avd_frame_record* records)
+{
+    const Nv12Arg a{y, uv, y_row_stride, uv_row_stride, y_frame_stride, uv_frame_stride};
+    return guarded(ctx, [&] { return impl_analyze_frames_nv12_async(ctx, a, mem, n, h, w, records); });
+}
+
+int avd_analyze_frames_nv12(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w,
+                            int64_t y_row_stride, int64_t uv_row_stride, int64_t y_frame_stride, int64_t uv_frame_stride,
+                            avd_frame_record* records)
+{
+    const Nv12Arg a{y, uv, y_row_stride, uv_row_stride, y_frame_stride, uv_frame_stride};
+    return guarded(ctx, [&] {
+        const int rc = impl_analyze_frames_nv12_async(ctx, a, mem, n, h, w, records);
+        return rc ? rc : impl_synchronize(ctx);
+    });
+}
 
 int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
                        int64_t frame_stride, avd_frame_record* records)

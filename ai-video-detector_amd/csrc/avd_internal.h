@@ -48,6 +48,18 @@ struct FbConsts {
 };
 void build_fb_consts(FbConsts& c);
 
+// libswscale's C yuv420 -> BGR24 conversion in integer form (avd_tables.cpp, yuv2rgb.c semantics, BT.601 limited):
+//   value = clip8((c0 + (Y + off) * cy) >> 16),  off_r = ((V*crv)>>16) - (crv>>9),  off_b likewise with U and cbu,
+//   off_g = ((U*cgu)>>16) - (cgu>>9) + ((V*cgv)>>16) - (cgv>>9)   (arithmetic shifts: cgu, cgv are negative)
+struct YuvConsts { int cy, crv, cbu, cgu, cgv, c0, kr, kb, kg; };   // kr = -(crv>>9), kb = -(cbu>>9), kg = -(cgu>>9) - (cgv>>9)
+void build_yuv_consts(YuvConsts& c);
+
+struct Nv12Params {
+    const uint8_t* uv;                 // interleaved U,V plane of frame 0 (the Y plane is the kernel's frame pointer)
+    int64_t uv_row_stride, uv_frame_stride;
+    YuvConsts k;
+};
+
 // ---- device-side parameter blocks ------------------------------------------------
 struct LinTap { short i0, i1, w0, w1; };   // two source indices + 11-bit weights of one output row/column
 
@@ -128,6 +140,9 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w);
 int avd_ws_reserve_fb(avd_ctx* ctx, int n);
 int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
                       int64_t row_stride, int64_t frame_stride);
+// NV12 input: Y plane rows at d_y + f*frame_stride + y*row_stride, chroma rows at nv.uv + f*uv_frame_stride + (y/2)*uv_row_stride
+int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& nv, int n, int h, int w,
+                           int64_t row_stride, int64_t frame_stride);
 int launch_hash(avd_ctx* ctx, int n);
 int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off);
 int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);

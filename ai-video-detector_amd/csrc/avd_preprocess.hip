@@ -470,6 +470,96 @@ __global__ __launch_bounds__(NT, 4) void k_preprocess_vec(const uint8_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// NV12 ingest: the decoder's surface goes straight into the fused pass.  Per pixel the BGR triple
+// that cv2.VideoCapture.retrieve() would have produced (libswscale's table-driven yuv2rgb.c, BT.601 limited range,
+// nearest chroma; reference app/analyzers/video.py:28-32) is formed in registers, reduced to cv2's 15-bit gray at
+// once and written to the LDS tile: neither BGR nor gray ever reaches HBM, and the frame costs 1.5 bytes per pixel
+// of HBM reads instead of 3.  Phases 2-4 are the BGR kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clip8(int v) { return min(max(v, 0), 255); }
+
+// chroma part of the three table lookups of one U,V pair: c0 + off * cy per channel
+struct ChromaTerms { int r, g, b; };
+__device__ __forceinline__ ChromaTerms chroma_terms(int U, int V, const YuvConsts& k)
+{
+    ChromaTerms t;
+    t.r = k.c0 + (((V * k.crv) >> 16) + k.kr) * k.cy;
+    t.b = k.c0 + (((U * k.cbu) >> 16) + k.kb) * k.cy;
+    t.g = k.c0 + (((U * k.cgu) >> 16) + ((V * k.cgv) >> 16) + k.kg) * k.cy;
+    return t;
+}
+
+__device__ __forceinline__ unsigned gray_from_yuv(int Y, const ChromaTerms& t, int cy)
+{
+    const int yl = Y * cy;
+    const unsigned B = (unsigned)clip8((yl + t.b) >> 16), G = (unsigned)clip8((yl + t.g) >> 16), R = (unsigned)clip8((yl + t.r) >> 16);
+    return (B * 3735u + G * 19235u + R * 9798u + (1u << 14)) >> 15;
+}
+
+// 4 luma bytes + 2 chroma pairs (U0 V0 U1 V1) -> 4 gray bytes
+__device__ __forceinline__ unsigned gray4_nv12(unsigned yw, unsigned cw, const YuvConsts& k)
+{
+    const ChromaTerms t0 = chroma_terms(cw & 0xFF, (cw >> 8) & 0xFF, k);
+    const ChromaTerms t1 = chroma_terms((cw >> 16) & 0xFF, cw >> 24, k);
+    return gray_from_yuv(yw & 0xFF, t0, k.cy) | (gray_from_yuv((yw >> 8) & 0xFF, t0, k.cy) << 8) |
+           (gray_from_yuv((yw >> 16) & 0xFF, t1, k.cy) << 16) | (gray_from_yuv(yw >> 24, t1, k.cy) << 24);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_preprocess_nv12(const uint8_t* __restrict__ yplane, Nv12Params nv, int n,
+                                                             PreParams P, uint8_t* __restrict__ small,
+                                                             float* __restrict__ rowbuf, long long* __restrict__ lap_part)
+{
+    extern __shared__ __align__(16) uint8_t tile[];
+    const int total = n * P.nbands;
+    const int lid = xcd_remap(blockIdx.x, total);
+    if (lid >= total) return;
+    const int f = lid / P.nbands;
+    const int band = lid - f * P.nbands;
+    const int h = P.h, w = P.w, pitch = P.pitch;
+    const int r0 = band * P.rows_per_band;
+    const int rows = min(P.rows_per_band, h - r0);
+    const int tid = threadIdx.x;
+    const uint8_t* yfr = yplane + (int64_t)f * P.frame_stride;
+    const uint8_t* cfr = nv.uv + (int64_t)f * nv.uv_frame_stride;
+    const int trows = rows + 2;                            // tile row 0 = image row r0-1
+    if (VEC) {
+        const int chunks = w >> 4;
+        for (int it = tid; it < trows * chunks; it += kThreads) {
+            const int tr = it / chunks, c = it - tr * chunks;
+            const int y = reflect_once(r0 - 1 + tr, h);
+            const uint4 yy = *reinterpret_cast<const uint4*>(yfr + (int64_t)y * P.row_stride + c * 16);
+            const uint4 cc = *reinterpret_cast<const uint4*>(cfr + (int64_t)(y >> 1) * nv.uv_row_stride + c * 16);
+            uint4 g;
+            g.x = gray4_nv12(yy.x, cc.x, nv.k); g.y = gray4_nv12(yy.y, cc.y, nv.k);
+            g.z = gray4_nv12(yy.z, cc.z, nv.k); g.w = gray4_nv12(yy.w, cc.w, nv.k);
+            *reinterpret_cast<uint4*>(tile + tr * pitch + kPad + c * 16) = g;
+        }
+    } else {
+        for (int it = tid; it < trows * w; it += kThreads) {
+            const int tr = it / w, x = it - tr * w;
+            const int y = reflect_once(r0 - 1 + tr, h);
+            const uint8_t* cp = cfr + (int64_t)(y >> 1) * nv.uv_row_stride + (x >> 1) * 2;
+            const ChromaTerms t = chroma_terms(cp[0], cp[1], nv.k);
+            tile[tr * pitch + kPad + x] = (uint8_t)gray_from_yuv(yfr[(int64_t)y * P.row_stride + x], t, nv.k.cy);
+        }
+    }
+    __syncthreads();
+    for (int tr = tid; tr < trows; tr += kThreads) {      // column halo (BORDER_REFLECT_101)
+        uint8_t* row = tile + tr * pitch + kPad;
+        row[-1] = row[reflect101(-1, w)];
+        row[w] = row[reflect101(w, w)];
+    }
+    __syncthreads();
+    const Moments m = band_phases<kThreads, false>(tile, nullptr, P, f, band, r0, rows, tid, small, rowbuf);
+    const long long s64 = wave_sum(m.s), q64 = wave_sum(m.q);
+    if ((tid & 63) == 0) {
+        long long* slot = lap_part + ((int64_t)lid * kLapSlots + (tid >> 6)) * 2;
+        slot[0] = s64; slot[1] = q64;
+    }
+}
+
 // 32x32 INTER_AREA cells from the per-row partials (vertical accumulation in cv2's row
 // order), then aHash bits: g >= mean(g)  <=>  1024*g >= sum(g)   (video.py:7-8)
 __global__ __launch_bounds__(1024) void k_hash(const float* __restrict__ rowbuf, HashParams P,
@@ -600,6 +690,31 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
             hipLaunchKernelGGL(k_preprocess<false>, dim3(grid), dim3(kThreads), lds, ctx->stream,
                                d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& nv, int n, int h, int w,
+                           int64_t row_stride, int64_t frame_stride)
+{
+    Workspace& ws = ctx->ws;
+    PreParams P = ws.pre;
+    P.row_stride = row_stride;
+    P.frame_stride = frame_stride;
+    P.dbg_skip = 0;
+    const int total = n * P.nbands;
+    const bool vec = (w % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && (nv.uv_row_stride % 16 == 0) &&
+                     (nv.uv_frame_stride % 16 == 0) && (reinterpret_cast<uintptr_t>(d_y) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(nv.uv) % 16 == 0);
+    const int grid = ((total + 7) / 8) * 8;
+    const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
+    ws.lap_waves = kThreads / 64;
+    if (vec)
+        hipLaunchKernelGGL(k_preprocess_nv12<true>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small,
+                           ws.d_rowbuf, ws.d_lap_part);
+    else
+        hipLaunchKernelGGL(k_preprocess_nv12<false>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small,
+                           ws.d_rowbuf, ws.d_lap_part);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

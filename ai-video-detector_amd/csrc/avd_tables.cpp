@@ -189,3 +189,23 @@ void build_fb_consts(FbConsts& c)
         gaussian_taps(ks, sig, c.gk[k]);
     }
 }
+
+// ---- NV12 ingest: libswscale's yuv2rgb.c table construction reduced to its integer constants ------------------
+// (ff_yuv2rgb_c_init_tables for a 24-bit destination, SWS_CS_DEFAULT = BT.601, limited range, neutral brightness /
+// contrast / saturation).  The tables themselves are not materialised: every entry is
+// clip_uint8((yb0 + i*cy + 0x8000) >> 16) and every chroma table is an index offset, so the kernel evaluates
+// value = clip8((c0 + (Y + off)*cy) >> 16) directly (the oracle keeps the literal tables and the two are compared).
+void build_yuv_consts(YuvConsts& c)
+{
+    const long long one = 1ll << 16;
+    const long long cy = one * 255 / 219;                    // luma gain of a limited-range source
+    const long long oy = 16ll << 16;
+    auto rescale = [&](long long inc) { return (inc * one + 0x8000) / cy; };      // "scale coefficients by cy"
+    const long long crv = rescale(104597), cbu = rescale(132201), cgu = rescale(-25675), cgv = rescale(-53279);
+    auto fl = [](long long v, int s) { return v >= 0 ? v >> s : -((-v + (1ll << s) - 1) >> s); };   // floor shift
+    c.cy = (int)cy; c.crv = (int)crv; c.cbu = (int)cbu; c.cgu = (int)cgu; c.cgv = (int)cgv;
+    c.c0 = (int)(-(384ll << 16) - oy + 326 * cy + 0x8000);   // table bias, luma offset of the limited-range tables, rounding
+    c.kr = (int)-fl(crv, 9);
+    c.kb = (int)-fl(cbu, 9);
+    c.kg = (int)(-fl(cgu, 9) - fl(cgv, 9));
+}

@@ -308,6 +308,27 @@ def main():
             run(reps, pinned)
             pcie_fps_inflight = reps * n / (time.perf_counter() - t1)
 
+    # NV12 ingest: the same clip as decoder surfaces (1.5 B per pixel), reported apart -- never `value`
+    nv12 = None
+    if not args.no_pcie and (h % 2 == 0 and w % 2 == 0):
+        k = min(n, 8)
+        ys, cs = synth.bgr_to_nv12(clip[:k])                  # a few distinct surfaces, cycled: the kernel time does not depend on content
+        idx = np.arange(n) % k
+        hy, hc = torch.from_numpy(ys[idx]).pin_memory(), torch.from_numpy(cs[idx]).pin_memory()
+        dy, dc = hy.to(dev), hc.to(dev)
+        c0 = ctxs[0]
+        rec_nv = c0.analyze_frames_nv12(dy, dc)
+        pre = []
+        for _ in range(10):
+            c0.analyze_frames_nv12(dy, dc)
+            pre.append(c0.stage_ms()[0])
+        t1 = time.perf_counter()
+        for _ in range(3):
+            c0.analyze_frames_nv12(hy, hc)
+        nv12 = {"pre_ms": statistics.median(pre), "host_fps": 3 * n / (time.perf_counter() - t1),
+                "flow_mean_head": [round(float(v), 6) for v in rec_nv["flow_mean"][1:3]]}
+        del dy, dc
+
     run(args.warmup)                  # W untimed warm-up steps in the timed region's own (pipelined) mode
     elapsed_all, timed_stage = [], np.zeros(6)
     result = fused = None
@@ -369,6 +390,16 @@ def main():
         if pcie_fps is not None:
             out["pcie_inclusive_fps"] = round(pcie_fps_inflight if pcie_fps_inflight is not None else pcie_fps, 1)
             out["pcie_inclusive_fps_one_clip_at_a_time"] = round(pcie_fps, 1)
+        if nv12 is not None:
+            nv_alg = n * (h * w * 3 // 2 + 320 * 320 + 1024 + 16)
+            nv_ach = nv_alg / (nv12["pre_ms"] * 1e-3) / 1e9
+            out["roofline_nv12_ingest"] = {
+                "kernel": "k_preprocess_nv12 (NV12 surface -> libswscale-style BGR in registers -> gray in LDS -> the fused phases; no BGR in HBM)",
+                "bound": "hbm", "achieved": round(nv_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nv_ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes_per_launch": nv_alg, "bytes_per_frame_read": h * w * 3 // 2,
+                "avg_launch_ms": round(nv12["pre_ms"], 4),
+                "bound_note": "VALU-bound: ~20 integer operations per pixel for the three clipped table values and the gray",
+                "pcie_inclusive_fps_one_clip_at_a_time": round(nv12["host_fps"], 1)}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(clip, meta, min(args.cpu_frames, n), max(1, min(args.cpu_procs, os.cpu_count() or 1)))
         else:

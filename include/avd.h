@@ -105,6 +105,26 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
                              avd_frame_record* records);
 int avd_synchronize(avd_ctx* ctx);
 
+/* NV12 input (decode -> ingest).  Hardware decoders (VCN / rocDecode) and most software decoders
+ * produce YUV 4:2:0, not BGR; the reference gets BGR because cv2.VideoCapture.retrieve() runs libswscale on the
+ * decoded picture (reference app/analyzers/video.py:28-32).  These entry points take the decoder's surface
+ * directly -- a Y plane uint8[h][w] and an interleaved U,V plane uint8[h/2][w], per frame at
+ * y + f*y_frame_stride + row*y_row_stride and uv + f*uv_frame_stride + (row/2)*uv_row_stride -- and form, per pixel
+ * and in registers, the BGR triple libswscale's C converter would have written (yuv2rgb.c tables: BT.601 limited
+ * range, nearest chroma) before cv2's BGR2GRAY: 1.5 bytes per pixel cross PCIe / HBM instead of 3, and no BGR frame
+ * exists anywhere.  Results equal avd_analyze_frames on the BGR frames of oracle/avd_oracle.c's avdo_nv12_to_bgr24
+ * bit for bit; parity with a real libswscale is UNPINNED (restated from memory, x86 builds also dispatch to SIMD
+ * code that differs by +-1).  Width and height must be even.  Outputs as for the BGR entry points. */
+int avd_preprocess_nv12(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w,
+                        int64_t y_row_stride, int64_t uv_row_stride, int64_t y_frame_stride, int64_t uv_frame_stride,
+                        uint8_t* small320, uint8_t* hash1024, int64_t* lap_sum, int64_t* lap_sumsq);
+int avd_analyze_frames_nv12(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w,
+                            int64_t y_row_stride, int64_t uv_row_stride, int64_t y_frame_stride, int64_t uv_frame_stride,
+                            avd_frame_record* records);
+int avd_analyze_frames_nv12_async(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w,
+                                  int64_t y_row_stride, int64_t uv_row_stride, int64_t y_frame_stride,
+                                  int64_t uv_frame_stride, avd_frame_record* records);
+
 /* Stream ordering for AVD_MEM_DEVICE inputs.  A context launches on its own non-blocking stream, so device memory
  * that another stream is still writing (e.g. torch's current stream: a freshly computed tensor, a .contiguous()
  * copy, a decoder's colour-conversion kernel) must be ordered explicitly: everything enqueued on `producer_stream`

@@ -805,6 +805,91 @@ int avdo_farneback(const uint8_t* prev, const uint8_t* next, int h, int w, float
     return 0;
 }
 
+/* ---------- NV12 -> BGR24 as libswscale's C converter does it (row N1: decode -> BGR ingest) ----------
+ * cv2.VideoCapture's FFmpeg backend hands `retrieve()` a BGR24 frame made by sws_scale from the decoder's YUV
+ * 4:2:0 picture (reference app/analyzers/video.py:28-32).  For equal sizes swscale takes its unscaled special
+ * converter, libswscale/yuv2rgb.c: table driven, nearest chroma (a 2x2 block shares U and V), BT.601 limited range
+ * for untagged streams (SWS_CS_DEFAULT).  Restated here from the published algorithm:
+ *   ff_yuv2rgb_c_init_tables(): coefficients {crv 104597, cbu 132201, cgu 25675, cgv 53279} (16.16), luma gain
+ *   cy = 65536*255/219, oy = 16<<16, chroma increments rescaled by 1/cy with rounding, a 1-D clipping table
+ *   y_table[i] = clip_uint8((yb + 0x8000) >> 16), yb = -(384<<16) - HEADROOM*cy - oy + i*cy, and per chroma value a
+ *   POINTER into that table: table_rV[V] = y_table + yoffs + ((V*crv)>>16) - (crv>>9) (fill_table), likewise bU, gU,
+ *   and an integer offset gV (fill_gv_table); yoffs = 326 + HEADROOM for limited range.
+ *   yuv2rgb_c_24_bgr(): dst[0] = b[Y], dst[1] = g[Y], dst[2] = r[Y] with r = table_rV[V], g = table_gU[U] + table_gV[V],
+ *   b = table_bU[U].
+ * PARITY UNPINNED twice over: there is no libswscale here to check the constants against (the 326 luma offset and the
+ * HEADROOM of 512 are from memory), and x86 builds of FFmpeg dispatch this conversion to SSSE3/AVX2 code whose 16-bit
+ * fixed-point arithmetic differs from the C tables by +-1 grey level.  NV12 (what hardware decoders emit) and planar
+ * yuv420p go through the same tables; only the chroma addressing differs. */
+#define YUVRGB_HEADROOM 512
+typedef struct {
+    uint8_t ytab[1024 + 2 * YUVRGB_HEADROOM];
+    int r_off[256], b_off[256], gu_off[256], gv_off[256];   /* offsets into ytab, relative to ytab + yoffs */
+    int yoffs;
+} Yuv2RgbTables;
+
+static int64_t asr64(int64_t v, int s) { return v >= 0 ? v >> s : -((-v + ((int64_t)1 << s) - 1) >> s); }   /* floor */
+
+static void yuv2rgb_init_tables(Yuv2RgbTables* t)
+{
+    int64_t crv = 104597, cbu = 132201, cgu = -25675, cgv = -53279;      /* ff_yuv2rgb_coeffs[SWS_CS_DEFAULT] */
+    int64_t cy = ((int64_t)1 << 16) * 255 / 219, oy = (int64_t)16 << 16;   /* limited range */
+    /* contrast = saturation = 1<<16, brightness = 0: the scaling steps are identities */
+    crv = (crv * 65536 + 0x8000) / cy;
+    cbu = (cbu * 65536 + 0x8000) / cy;
+    cgu = (cgu * 65536 + 0x8000) / cy;           /* C division truncates toward zero, as in the original */
+    cgv = (cgv * 65536 + 0x8000) / cy;
+    int64_t yb = -((int64_t)384 << 16) - YUVRGB_HEADROOM * cy - oy;
+    for (int i = 0; i < 1024 + 2 * YUVRGB_HEADROOM; i++) {
+        int64_t v = asr64(yb + 0x8000, 16);
+        t->ytab[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        yb += cy;
+    }
+    t->yoffs = 326 + YUVRGB_HEADROOM;
+    for (int i = 0; i < 256; i++) {
+        t->r_off[i] = (int)(asr64(i * crv, 16) - asr64(crv, 9));
+        t->b_off[i] = (int)(asr64(i * cbu, 16) - asr64(cbu, 9));
+        t->gu_off[i] = (int)(asr64(i * cgu, 16) - asr64(cgu, 9));
+        t->gv_off[i] = (int)(asr64(i * cgv, 16) - asr64(cgv, 9));
+    }
+}
+
+/* the integer constants of the conversion, for a kernel that evaluates the tables arithmetically:
+ * out[0..5] = cy, crv, cbu, cgu, cgv (after rescaling), c0 with  value = clip8((c0 + (Y + off) * cy) >> 16) */
+void avdo_yuv2rgb_consts(int64_t out[6])
+{
+    int64_t crv = 104597, cbu = 132201, cgu = -25675, cgv = -53279;
+    int64_t cy = ((int64_t)1 << 16) * 255 / 219, oy = (int64_t)16 << 16;
+    out[0] = cy;
+    out[1] = (crv * 65536 + 0x8000) / cy;
+    out[2] = (cbu * 65536 + 0x8000) / cy;
+    out[3] = (cgu * 65536 + 0x8000) / cy;
+    out[4] = (cgv * 65536 + 0x8000) / cy;
+    out[5] = -((int64_t)384 << 16) - oy + 326 * cy + 0x8000;
+}
+
+int avdo_nv12_to_bgr24(const uint8_t* yp, const uint8_t* uvp, int h, int w, int64_t y_stride, int64_t uv_stride,
+                       uint8_t* bgr, int64_t bgr_stride)
+{
+    static Yuv2RgbTables T;
+    static int ready = 0;
+    if ((h & 1) || (w & 1) || h <= 0 || w <= 0) return -1;
+    if (!ready) { yuv2rgb_init_tables(&T); ready = 1; }
+    for (int y = 0; y < h; y++) {
+        const uint8_t* Y = yp + (int64_t)y * y_stride;
+        const uint8_t* C = uvp + (int64_t)(y >> 1) * uv_stride;
+        uint8_t* D = bgr + (int64_t)y * bgr_stride;
+        for (int x = 0; x < w; x++) {
+            const int U = C[(x >> 1) * 2], V = C[(x >> 1) * 2 + 1];
+            const uint8_t* r = T.ytab + T.yoffs + T.r_off[V];
+            const uint8_t* g = T.ytab + T.yoffs + T.gu_off[U] + T.gv_off[V];
+            const uint8_t* b = T.ytab + T.yoffs + T.b_off[U];
+            D[3 * x] = b[Y[x]]; D[3 * x + 1] = g[Y[x]]; D[3 * x + 2] = r[Y[x]];
+        }
+    }
+    return 0;
+}
+
 /* ---------- frame-level twins of include/avd.h ---------- */
 int avdo_preprocess_bgr(const uint8_t* bgr, int n, int h, int w, int64_t row_stride,
                         int64_t frame_stride, uint8_t* small320, uint8_t* hash1024,

@@ -63,6 +63,10 @@ def lib() -> C.CDLL:
         L.avdo_preprocess_bgr.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                           u8p, u8p, i64p, i64p]
         L.avdo_farneback_pairs.argtypes = [u8p, C.c_int, f32p, f32p]
+        L.avdo_nv12_to_bgr24.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int64, C.c_int64, u8p, C.c_int64]
+        L.avdo_nv12_to_bgr24.restype = C.c_int
+        L.avdo_yuv2rgb_consts.argtypes = [i64p]
+        L.avdo_yuv2rgb_consts.restype = None
         L.avdo_set_model.argtypes = [C.c_int]
         L.avdo_set_model.restype = None
         L.avdo_get_model.restype = C.c_int
@@ -241,6 +245,28 @@ def update_flow_blur(R0, R1, flow, M, block_size=15, update=True):
 
 
 # ---- frame-level twins of the product C-ABI (include/avd.h) -------------------------
+def nv12_to_bgr(y: np.ndarray, uv: np.ndarray) -> np.ndarray:
+    """libswscale's C yuv420 -> BGR24 (BT.601 limited range, nearest chroma) for NV12 planes:
+    y uint8[..., H, W], uv uint8[..., H/2, W] (U, V interleaved) -> uint8[..., H, W, 3]."""
+    y = np.ascontiguousarray(y, np.uint8)
+    uv = np.ascontiguousarray(uv, np.uint8)
+    h, w = y.shape[-2:]
+    assert uv.shape[-2:] == (h // 2, w) and h % 2 == 0 and w % 2 == 0
+    out = np.empty(y.shape + (3,), np.uint8)
+    yy, cc, oo = y.reshape(-1, h, w), uv.reshape(-1, h // 2, w), out.reshape(-1, h, w, 3)
+    for i in range(len(yy)):
+        rc = lib().avdo_nv12_to_bgr24(_p(yy[i], C.c_uint8), _p(cc[i], C.c_uint8), h, w, w, w, _p(oo[i], C.c_uint8), 3 * w)
+        if rc:
+            raise ValueError("avdo_nv12_to_bgr24 failed")
+    return out
+
+
+def yuv2rgb_consts():
+    out = np.zeros(6, np.int64)
+    lib().avdo_yuv2rgb_consts(_p(out, C.c_int64))
+    return {k: int(v) for k, v in zip(("cy", "crv", "cbu", "cgu", "cgv", "c0"), out)}
+
+
 def preprocess_bgr(frames: np.ndarray):
     """frames uint8[N,H,W,3] -> (small u8[N,320,320], hash u8[N,1024], lap_sum i64[N], lap_sumsq i64[N])"""
     frames = _c(frames, np.uint8)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes (counter_collection.csv) -> profiles/rNN_pmc.json: mean per launch and kernel.
+usage: pmc_to_json.py OUT.json LABEL DIR [DIR...]   (every DIR holds one pass; counters of all passes are merged)
+FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads
+(MI355X_MICROARCH.md, HBM): hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE, as the guide prescribes."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+out_path, label, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in dirs:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"]
+            name = re.sub(r"\(anonymous namespace\)::", "", name)
+            name = re.sub(r"^void ", "", name)
+            name = re.sub(r"\(.*$", "", name)
+            acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+kernels = {}
+for name, ctr in sorted(acc.items()):
+    k = {"launches": max(len(v) for v in ctr.values())}
+    for c, v in sorted(ctr.items()):
+        k[c] = sum(v) / len(v)
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        k["fetch_bytes_x2"] = 2 * 1024 * k["FETCH_SIZE"]
+        k["write_bytes"] = 1024 * k["WRITE_SIZE"]
+        k["hbm_bytes"] = k["fetch_bytes_x2"] + k["write_bytes"]
+    kernels[name] = k
+res = {"label": label, "note": "mean per launch; FETCH_SIZE / WRITE_SIZE in KiB, separate --pmc passes without tracing domains; "
+                               "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide); SQ_* cycle counters count quad-cycles",
+       "kernels": kernels}
+# short names bench.py looks up
+for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_preprocess_vec", r"k_preprocess")):
+    for name, k in kernels.items():
+        if re.search(pat, name) and "hbm_bytes" in k:
+            res[short] = {"hbm_bytes": k["hbm_bytes"], "kernel": name}
+fb = [k for n, k in kernels.items() if re.search(r"k_fb_level|k_pyramid|k_polyexp|k_flow_up|k_stats|k_uv|k_hscan", n) and "hbm_bytes" in k]
+if fb:
+    # per clip: launches per clip = launches / clips in the trace; every kernel above is launched a fixed number of times per clip
+    clips = min(k["launches"] for n, k in kernels.items() if re.search(r"k_fb_level<320", n)) or 1
+    res["farneback_stage"] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for k in fb) / clips, "clips_in_trace": clips}
+    res["whole_clip"] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for k in kernels.values() if "hbm_bytes" in k) / clips}
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
