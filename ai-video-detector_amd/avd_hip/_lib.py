@@ -25,6 +25,7 @@ EXPORTS = (
     "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
     "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
+    "avd_vit_set_weights", "avd_vit_patch_embed",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
@@ -32,6 +33,16 @@ EXPORTS = (
 # numpy view of struct avd_frame_record (32 bytes)
 RECORD_DTYPE = np.dtype([("lap_sum", "<i8"), ("lap_sumsq", "<i8"), ("flow_mean", "<f4"),
                          ("flow_var", "<f4"), ("ham", "<i4"), ("reserved", "<i4")])
+
+
+def f32_to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns (uint16), round to nearest even (finite inputs)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
 
 
 class AvdError(RuntimeError):
@@ -95,6 +106,9 @@ def load() -> C.CDLL:
     L.avd_preprocess_nv12.argtypes = nv12 + [u8p, u8p, i64p, i64p]
     L.avd_analyze_frames_nv12.argtypes = nv12 + [vp]
     L.avd_analyze_frames_nv12_async.argtypes = nv12 + [vp]
+    L.avd_vit_set_weights.argtypes = [vp, vp, vp]
+    L.avd_vit_patch_embed.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.c_int,
+                                      C.POINTER(C.c_float)]
     L.avd_synchronize.argtypes = [vp]
     L.avd_wait_stream.argtypes = [vp, vp]
     L.avd_release_workspace.argtypes = [vp]
@@ -267,6 +281,30 @@ class Context:
         assert rec.dtype == RECORD_DTYPE and rec.size >= n and rec.flags.c_contiguous
         self._check(self._L.avd_analyze_frames_nv12_async(self._h, yp, cp, mem, n, h, w, yr, cr, yf, cf, rec.ctypes.data))
         return keep
+
+    # -- ViT-B/16 patch embedding (extension, never part of ai_score) ------------------------------------------
+    def vit_set_weights(self, weight: np.ndarray, bias=None):
+        """weight float32[768, 768] ([out][c*256 + py*16 + px]) -> rounded to bf16 (nearest even); bias float32[768]."""
+        wbits = f32_to_bf16_bits(np.ascontiguousarray(weight, np.float32).reshape(768, 768))
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32).reshape(768)
+        self._check(self._L.avd_vit_set_weights(self._h, wbits.ctypes.data, None if b is None else b.ctypes.data))
+
+    def vit_patch_embed(self, frames, timing_reps: int = 0, out=None):
+        """-> (tokens float32[N,196,768], gemm_ms or None).  ``out``: optional torch-ROCm float32 tensor [N,196,768]
+        to receive the tokens in HBM (nothing is copied to the host then)."""
+        ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
+        ms = C.c_float(0.0)
+        if out is not None:
+            if not (_is_torch_tensor(out) and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (n, 196, 768)
+                    and str(out.dtype) == "torch.float32"):
+                raise ValueError("out must be a contiguous float32 cuda tensor [N,196,768]")
+            self._after_torch_stream(out)
+            tptr, tmem, tokens = out.data_ptr(), AVD_MEM_DEVICE, out
+        else:
+            tokens = np.empty((n, 196, 768), np.float32)
+            tptr, tmem = tokens.ctypes.data, AVD_MEM_HOST
+        self._check(self._L.avd_vit_patch_embed(self._h, ptr, mem, n, h, w, rs, fs, tptr, tmem, int(timing_reps), C.byref(ms)))
+        return tokens, (float(ms.value) if timing_reps > 0 else None)
 
     def analyze_frames_async(self, frames, rec: np.ndarray):
         ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)

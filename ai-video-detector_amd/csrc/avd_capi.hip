@@ -61,6 +61,7 @@ void free_ws(Workspace& ws)
     F(ws.d_tables);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
+    F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     if (ws.h_rec) (void)hipHostFree(ws.h_rec);
     ws = Workspace{};
 }
@@ -609,6 +610,67 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     return AVD_ERR_ARG;
 }
 
+// ---- ViT-B/16 patch embedding (extension; never part of ai_score) ---------------------------------------------
+static int impl_vit_set_weights(avd_ctx* ctx, const uint16_t* w_bf16, const float* bias)
+{
+    if (!ctx || !w_bf16) return AVD_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Workspace& ws = ctx->ws;
+    if (!ws.d_vit_w) if (int e = dev_alloc(ctx, ws.d_vit_w, (size_t)768 * 768)) return e;
+    if (!ws.d_vit_bias) if (int e = dev_alloc(ctx, ws.d_vit_bias, (size_t)768)) return e;
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_vit_w, w_bf16, sizeof(uint16_t) * 768 * 768, hipMemcpyHostToDevice, ctx->stream));
+    if (bias) HIP_TRY(ctx, hipMemcpyAsync(ws.d_vit_bias, bias, sizeof(float) * 768, hipMemcpyHostToDevice, ctx->stream));
+    ws.vit_has_bias = bias != nullptr;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+
+static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
+                                int64_t frame_stride, float* tokens, int tokens_mem, int reps, float* gemm_ms)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if ((!bgr || !tokens) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    if (n < 0 || h < 2 || w < 2 || row_stride < (int64_t)w * 3) { ctx->err = "bad frame geometry"; return AVD_ERR_ARG; }
+    if (tokens_mem != AVD_MEM_HOST && tokens_mem != AVD_MEM_DEVICE) { ctx->err = "tokens_mem must be AVD_MEM_HOST or AVD_MEM_DEVICE"; return AVD_ERR_ARG; }
+    if (n == 0) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Workspace& ws = ctx->ws;
+    if (!ws.d_vit_w) { ctx->err = "avd_vit_set_weights has not been called"; return AVD_ERR_ARG; }
+    const size_t m = (size_t)n * 196;
+    if (ws.vit_patch_elems < m * 768) {
+        if (int e = dev_alloc(ctx, ws.d_vit_patches, m * 768)) return e;
+        ws.vit_patch_elems = m * 768;
+    }
+    float* d_tok = tokens;
+    if (tokens_mem == AVD_MEM_HOST) {
+        if (ws.vit_token_elems < m * 768) {
+            if (int e = dev_alloc(ctx, ws.d_vit_tokens, m * 768)) return e;
+            ws.vit_token_elems = m * 768;
+        }
+        d_tok = ws.d_vit_tokens;
+    }
+    const uint8_t* d_bgr = nullptr;
+    const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
+    if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
+    const float* d_bias = ws.vit_has_bias ? ws.d_vit_bias : nullptr;
+    if (int e = launch_vit_patch_embed(ctx, d_bgr, n, h, w, row_stride, frame_stride, ws.d_vit_w, d_bias, d_tok, ws.d_vit_patches)) return e;
+    if (reps > 0 && gemm_ms) {
+        // the GEMM alone, `reps` launches between two events on the context's stream (the patches stay resident)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int r = 0; r < reps; r++)
+            if (int e = launch_gemm_bf16_nt(ctx, ws.d_vit_patches, ws.d_vit_w, d_bias, d_tok, (int)m, 768, 768)) return e;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *gemm_ms = ms / reps;
+    }
+    if (tokens_mem == AVD_MEM_HOST)
+        HIP_TRY(ctx, hipMemcpyAsync(tokens, d_tok, sizeof(float) * m * 768, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+
 // Nothing may propagate across the C boundary: std::vector / std::string members of the context and the table
 // builders can throw std::bad_alloc (or length_error), so every entry point runs inside this guard.
 template <typename F>
@@ -692,6 +754,17 @@ int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, 
                        int64_t frame_stride, avd_frame_record* records)
 {
     return guarded(ctx, [&] { return impl_analyze_frames(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records); });
+}
+
+int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* bias)
+{
+    return guarded(ctx, [&] { return impl_vit_set_weights(ctx, weight_bf16, bias); });
+}
+
+int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
+                        float* tokens, int tokens_mem, int timing_reps, float* gemm_ms)
+{
+    return guarded(ctx, [&] { return impl_vit_patch_embed(ctx, bgr, mem, n, h, w, row_stride, frame_stride, tokens, tokens_mem, timing_reps, gemm_ms); });
 }
 
 int avd_wait_stream(avd_ctx* ctx, void* producer_stream) { return guarded(ctx, [&] { return impl_wait_stream(ctx, producer_stream); }); }

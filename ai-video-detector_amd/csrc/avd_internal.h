@@ -111,6 +111,10 @@ struct Workspace {
     float* d_part = nullptr;              // [n-1][2][13] per-buffer partial sums (numpy reduction order)
     avd_frame_record* d_rec = nullptr;    // [n]
     avd_frame_record* h_rec = nullptr;    // [n] pinned landing buffer of the asynchronous copy-out
+    // ViT patch-embed extension (avd_vit.hip): weights [768][768] bf16 + bias, im2col patches, token staging
+    uint16_t* d_vit_w = nullptr; float* d_vit_bias = nullptr; int vit_has_bias = 0;
+    uint16_t* d_vit_patches = nullptr; size_t vit_patch_elems = 0;
+    float* d_vit_tokens = nullptr; size_t vit_token_elems = 0;
 };
 
 struct avd_ctx {
@@ -146,5 +150,9 @@ int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& n
 int launch_hash(avd_ctx* ctx, int n);
 int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off);
 int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);
+// avd_vit.hip (extension): patchify + bf16 MFMA GEMM; all pointers device
+int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
+                           const uint16_t* d_wt, const float* d_bias, float* d_tokens, uint16_t* d_patches);
+int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, float* d_c, int M, int N, int K);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
 int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations);

@@ -179,6 +179,7 @@ def main():
                     help="processes of the clip-parallel CPU baseline (capped at the host's cores; 1 = single thread only)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
+    ap.add_argument("--no-vit", action="store_true", help="skip the ViT patch-embed MFMA measurement (an extension, reported apart)")
     ap.add_argument("--pcie", action="store_true", help="accepted for compatibility (the PCIe-inclusive figures are on by default)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="clips in flight per GPU, each on its own avd context / stream / workspace / input copy.  3 (default) = "
@@ -329,6 +330,22 @@ def main():
                 "flow_mean_head": [round(float(v), 6) for v in rec_nv["flow_mean"][1:3]]}
         del dy, dc
 
+    # ViT-B/16 patch-embed MFMA stage (a build-defined extension, NOT part of `value`): the GEMM
+    # [M = frames x 196, 768] x [768, 768] on 8 x the clip's frames (a shape that fills the chip several times over)
+    vit = None
+    if not args.no_vit and world == 1:
+        rngv = np.random.default_rng(7)
+        ctxs[0].vit_set_weights((rngv.standard_normal((768, 768)) * 0.02).astype(np.float32),
+                                (rngv.standard_normal(768) * 0.1).astype(np.float32))
+        big = frames[0].repeat(8, 1, 1, 1) if n * 8 * h * w * 3 < 16e9 else frames[0]
+        tok = torch.empty((big.shape[0], 196, 768), dtype=torch.float32, device=dev)
+        ctxs[0].vit_patch_embed(big, timing_reps=3, out=tok)
+        t1 = time.perf_counter()
+        _, gemm_ms = ctxs[0].vit_patch_embed(big, timing_reps=20, out=tok)
+        vit = {"frames": int(big.shape[0]), "gemm_ms": gemm_ms, "whole_call_ms": (time.perf_counter() - t1) * 1e3 - 20 * gemm_ms,
+               "checksum": float(tok[0, 0, :8].sum().item())}
+        del big, tok
+
     run(args.warmup)                  # W untimed warm-up steps in the timed region's own (pipelined) mode
     elapsed_all, timed_stage = [], np.zeros(6)
     result = fused = None
@@ -400,6 +417,18 @@ def main():
                 "avg_launch_ms": round(nv12["pre_ms"], 4),
                 "bound_note": "VALU-bound: ~20 integer operations per pixel for the three clipped table values and the gray",
                 "pcie_inclusive_fps_one_clip_at_a_time": round(nv12["host_fps"], 1)}
+        if vit is not None:
+            mm = vit["frames"] * 196
+            fl = 2.0 * mm * 768 * 768
+            tf = fl / (vit["gemm_ms"] * 1e-3) / 1e12
+            out["mfma_patch_embed"] = {
+                "kernel": "k_gemm_bf16_nt (ViT-B/16 patch embedding: [frames x 196, 768] x [768, 768], bf16 in, f32 accumulate, "
+                          "v_mfma_f32_16x16x32_bf16, 256x256 tiles, LDS-DMA staging)",
+                "extension": "no reference counterpart (the reference has no learned model); seeded random weights; not part of value / ai_score",
+                "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                "M": mm, "N": 768, "K": 768, "flops_per_launch": fl, "avg_launch_ms": round(vit["gemm_ms"], 4),
+                "frames_per_launch": vit["frames"], "patchify_plus_call_overhead_ms": round(vit["whole_call_ms"], 3),
+                "timed": "20 launches between two HIP events on the library's stream, patches resident in HBM"}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(clip, meta, min(args.cpu_frames, n), max(1, min(args.cpu_procs, os.cpu_count() or 1)))
         else:

@@ -125,6 +125,19 @@ int avd_analyze_frames_nv12_async(avd_ctx* ctx, const uint8_t* y, const uint8_t*
                                   int64_t y_row_stride, int64_t uv_row_stride, int64_t y_frame_stride,
                                   int64_t uv_frame_stride, avd_frame_record* records);
 
+/* ViT-B/16 patch embedding on the matrix cores -- a BUILD-DEFINED EXTENSION.  The reference
+ * contains no learned model (its per-frame "model" is the closed form of app/analyzers/video.py:54-56); BASELINE.json's
+ * north_star / configs[3] ask for this stage, so it exists, with caller-supplied weights, and is never part of
+ * ai_score / timeline.  avd_vit_set_weights: weight_bf16 = bf16 bits [768 out][768 in], in = c*256 + py*16 + px (the
+ * layout of a [768][3][16][16] conv weight, channels RGB), bias float[768] or NULL; both host pointers, copied.
+ * avd_vit_patch_embed: each BGR frame is resized to 224x224 (bilinear), normalised ((x/255 - mean)/std, ImageNet
+ * constants), cut into 196 patches of 16x16x3, rounded to bf16 and multiplied with the weights (f32 accumulation):
+ * tokens float[n][196][768], host or device (tokens_mem).  If timing_reps > 0 and gemm_ms != NULL the GEMM kernel alone
+ * is launched timing_reps more times between two HIP events and its mean duration is returned (bench hook). */
+int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* bias);
+int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
+                        int64_t frame_stride, float* tokens, int tokens_mem, int timing_reps, float* gemm_ms);
+
 /* Stream ordering for AVD_MEM_DEVICE inputs.  A context launches on its own non-blocking stream, so device memory
  * that another stream is still writing (e.g. torch's current stream: a freshly computed tensor, a .contiguous()
  * copy, a decoder's colour-conversion kernel) must be ordered explicitly: everything enqueued on `producer_stream`

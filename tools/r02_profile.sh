@@ -4,12 +4,12 @@
 # profiles/ by hand.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-B="--steps 5 --warmup 2 --cpu-frames 0 --repeats 1 --no-pcie"
+B="--steps 5 --warmup 2 --cpu-frames 0 --repeats 1 --no-pcie --no-vit"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_kt1 -- python3 $R/bench.py --inflight 1 $B > $R/gpurun_out/r02_kt1.log 2>&1 || exit 1
 echo kt1 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_kt3 -- python3 $R/bench.py $B > $R/gpurun_out/r02_kt3.log 2>&1 || exit 1
 echo kt3 done
-P="--inflight 1 --steps 2 --warmup 1 --cpu-frames 0 --repeats 1 --no-pcie"
+P="--inflight 1 --steps 2 --warmup 1 --cpu-frames 0 --repeats 1 --no-pcie --no-vit"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r02_pmc_fetch -- python3 $R/bench.py $P > $R/gpurun_out/r02_pmc_fetch.log 2>&1 || exit 1
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r02_pmc_write -- python3 $R/bench.py $P > $R/gpurun_out/r02_pmc_write.log 2>&1 || exit 1
