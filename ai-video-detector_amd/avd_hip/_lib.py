@@ -25,10 +25,14 @@ EXPORTS = (
     "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
     "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
-    "avd_vit_set_weights", "avd_vit_patch_embed",
+    "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
+
+# numpy view of struct avd_audio_window (48 bytes)
+AUDIO_WINDOW_DTYPE = np.dtype([("sumsq", "<f8"), ("sum_log", "<f8"), ("sum_mag", "<f8"), ("sum_fmag", "<f8"),
+                               ("zero_cross", "<i4"), ("length", "<i4"), ("rolloff_index", "<i4"), ("nbins", "<i4")])
 
 # numpy view of struct avd_frame_record (32 bytes)
 RECORD_DTYPE = np.dtype([("lap_sum", "<i8"), ("lap_sumsq", "<i8"), ("flow_mean", "<f4"),
@@ -109,6 +113,7 @@ def load() -> C.CDLL:
     L.avd_vit_set_weights.argtypes = [vp, vp, vp]
     L.avd_vit_patch_embed.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.c_int,
                                       C.POINTER(C.c_float)]
+    L.avd_audio_features.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int]
     L.avd_synchronize.argtypes = [vp]
     L.avd_wait_stream.argtypes = [vp, vp]
     L.avd_release_workspace.argtypes = [vp]
@@ -305,6 +310,26 @@ class Context:
             tptr, tmem = tokens.ctypes.data, AVD_MEM_HOST
         self._check(self._L.avd_vit_patch_embed(self._h, ptr, mem, n, h, w, rs, fs, tptr, tmem, int(timing_reps), C.byref(ms)))
         return tokens, (float(ms.value) if timing_reps > 0 else None)
+
+    # -- audio analyzer (reference app/analyzers/audio.py:40-61 for all windows at once) -----------------------
+    def audio_features(self, wav, win: int) -> np.ndarray:
+        """wav: mono float32 samples (numpy or torch-ROCm tensor) -> structured array (AUDIO_WINDOW_DTYPE) per window."""
+        if _is_torch_tensor(wav):
+            t = wav.contiguous()
+            if str(t.dtype) != "torch.float32" or t.dim() != 1:
+                raise ValueError("wav must be float32[n]")
+            if t.is_cuda:
+                self._after_torch_stream(t)
+            ptr, mem, n, keep = t.data_ptr(), (AVD_MEM_DEVICE if t.is_cuda else AVD_MEM_HOST), int(t.numel()), t
+        else:
+            a = np.ascontiguousarray(wav, dtype=np.float32)
+            if a.ndim != 1:
+                raise ValueError("wav must be float32[n]")
+            ptr, mem, n, keep = a.ctypes.data, AVD_MEM_HOST, int(a.size), a
+        nwin = (n + win - 1) // win if n else 0
+        out = np.zeros(nwin, AUDIO_WINDOW_DTYPE)
+        self._check(self._L.avd_audio_features(self._h, ptr, mem, n, int(win), out.ctypes.data, nwin))
+        return out
 
     def analyze_frames_async(self, frames, rec: np.ndarray):
         ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)

@@ -21,6 +21,7 @@ import subprocess
 import traceback
 from typing import Any, Callable, Dict, Optional
 
+from app.analyzers import audio as audio_an
 from app.analyzers import fusion as fusion_an
 from app.analyzers import heuristics_v2 as hx
 from app.analyzers import video as video_an
@@ -87,7 +88,7 @@ def _tlen(meta: dict) -> int:
 
 def audio_unavailable(path: str, meta: dict) -> dict:
     """What the reference's audio analyzer returns when it cannot run (audio.py:112-118): a
-    neutral timeline and an error flag.  Used when no audio analyzer is plugged in."""
+    neutral timeline and an error flag (bench.py uses it: its synthetic clips have no sound track)."""
     return {"scores": {}, "flags_audio": {"error": "audio analyzer not available in this build"},
             "timeline": [0.5] * _tlen(meta)}
 
@@ -133,7 +134,7 @@ def analyze_path(path: str, meta: Optional[dict] = None, *, audio_analyzer: Opti
     for k in META_KEYS:
         meta.setdefault(k, None if k in ("vcodec", "acodec", "format_name") else 0)
     hints = hx.compute_hints(meta, path)
-    audio, a_hint = safe_call("audio", audio_analyzer or audio_unavailable, path, meta, debug)
+    audio, a_hint = safe_call("audio", audio_analyzer or audio_an.analyze, path, meta, debug)
     video, v_hint = safe_call("video", video_analyzer or video_an.analyze, path, meta, debug)
     hints.update(a_hint)
     hints.update(v_hint)

@@ -62,6 +62,7 @@ void free_ws(Workspace& ws)
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
+    F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
     if (ws.h_rec) (void)hipHostFree(ws.h_rec);
     ws = Workspace{};
 }
@@ -671,6 +672,29 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     return AVD_OK;
 }
 
+// ---- audio analyzer (row N3) -------------------------------------------------------------------------------------
+static int impl_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (n < 0 || win < 1 || (n > 0 && (!wav || !windows))) { ctx->err = "bad arguments"; return AVD_ERR_ARG; }
+    if (n == 0) return AVD_OK;
+    const int64_t nw64 = (n + win - 1) / win;
+    if (nw64 > max_windows || nw64 > (1 << 24)) { ctx->err = "windows array too small"; return AVD_ERR_ARG; }
+    const int nwin = (int)nw64;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Workspace& ws = ctx->ws;
+    const uint8_t* d_wav = nullptr;
+    if (int e = stage_input(ctx, reinterpret_cast<const uint8_t*>(wav), mem, (size_t)n * sizeof(float), &d_wav)) return e;
+    if (ws.audio_out_elems < (size_t)nwin) {
+        if (int e = dev_alloc(ctx, ws.d_audio_out, (size_t)nwin)) return e;
+        ws.audio_out_elems = (size_t)nwin;
+    }
+    if (int e = launch_audio_features(ctx, reinterpret_cast<const float*>(d_wav), n, win, ws.d_audio_out, nwin)) return e;
+    HIP_TRY(ctx, hipMemcpyAsync(windows, ws.d_audio_out, sizeof(avd_audio_window) * nwin, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+
 // Nothing may propagate across the C boundary: std::vector / std::string members of the context and the table
 // builders can throw std::bad_alloc (or length_error), so every entry point runs inside this guard.
 template <typename F>
@@ -765,6 +789,11 @@ int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h,
                         float* tokens, int tokens_mem, int timing_reps, float* gemm_ms)
 {
     return guarded(ctx, [&] { return impl_vit_patch_embed(ctx, bgr, mem, n, h, w, row_stride, frame_stride, tokens, tokens_mem, timing_reps, gemm_ms); });
+}
+
+int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows)
+{
+    return guarded(ctx, [&] { return impl_audio_features(ctx, wav, mem, n, win, windows, max_windows); });
 }
 
 int avd_wait_stream(avd_ctx* ctx, void* producer_stream) { return guarded(ctx, [&] { return impl_wait_stream(ctx, producer_stream); }); }

@@ -115,6 +115,10 @@ struct Workspace {
     uint16_t* d_vit_w = nullptr; float* d_vit_bias = nullptr; int vit_has_bias = 0;
     uint16_t* d_vit_patches = nullptr; size_t vit_patch_elems = 0;
     float* d_vit_tokens = nullptr; size_t vit_token_elems = 0;
+    // audio analyzer (avd_audio.hip): tables (hanning, twiddles) for the current window lengths, scratch, records
+    double* d_audio_tab = nullptr; size_t audio_tab_elems = 0; int audio_win = 0, audio_last = 0;
+    double* d_audio_buf = nullptr; size_t audio_buf_elems = 0;
+    avd_audio_window* d_audio_out = nullptr; size_t audio_out_elems = 0;
 };
 
 struct avd_ctx {
@@ -154,5 +158,7 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
 int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
                            const uint16_t* d_wt, const float* d_bias, float* d_tokens, uint16_t* d_patches);
 int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, float* d_c, int M, int N, int K);
+// avd_audio.hip: per-window features of a mono float32 waveform (device pointers)
+int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, avd_audio_window* d_out, int nwin);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
 int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations);

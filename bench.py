@@ -346,6 +346,25 @@ def main():
                "checksum": float(tok[0, 0, :8].sum().item())}
         del big, tok
 
+    # audio analyzer, reported apart: the clip's 60 s sound track as 120 half-second windows
+    audio = None
+    if not args.no_vit and world == 1:
+        from avd_hip import audio as host_audio
+        rnga = np.random.default_rng(11)
+        ta = np.arange(int(16000 * meta["duration"])) / 16000.0
+        wave_f32 = (0.3 * np.sin(2 * np.pi * 140.0 * ta) * (np.sin(2 * np.pi * 0.9 * ta) > -0.2) + 0.05 * rnga.standard_normal(ta.size)).astype(np.float32)
+        dwave = torch.from_numpy(wave_f32).to(dev)
+        ctxs[0].audio_features(dwave, 8000)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            reca = ctxs[0].audio_features(dwave, 8000)
+        dt_feat = (time.perf_counter() - t1) / 5
+        t1 = time.perf_counter()
+        res_a = host_audio.features_to_result(host_audio.window_values(reca), len(wave_f32) / 16000.0)
+        audio = {"windows": int(len(reca)), "features_ms": dt_feat * 1e3, "tail_ms": (time.perf_counter() - t1) * 1e3,
+                 "speech_ratio": res_a["scores"]["speech_ratio"]}
+        del dwave
+
     run(args.warmup)                  # W untimed warm-up steps in the timed region's own (pipelined) mode
     elapsed_all, timed_stage = [], np.zeros(6)
     result = fused = None
@@ -429,6 +448,12 @@ def main():
                 "M": mm, "N": 768, "K": 768, "flops_per_launch": fl, "avg_launch_ms": round(vit["gemm_ms"], 4),
                 "frames_per_launch": vit["frames"], "patchify_plus_call_overhead_ms": round(vit["whole_call_ms"], 3),
                 "timed": "20 launches between two HIP events on the library's stream, patches resident in HBM"}
+        if audio is not None:
+            out["audio_analyzer"] = {
+                "what": "avd_audio_features: RMS / zero crossings / Hann + direct 8000-point real DFT in double / flatness, roll-off, centroid "
+                        "sums for every half-second window of a 60 s 16 kHz sound track in one call (reference audio.py:40-61), reported apart",
+                "windows": audio["windows"], "gpu_call_ms": round(audio["features_ms"], 3), "host_tail_ms": round(audio["tail_ms"], 3),
+                "windows_per_s": round(audio["windows"] / (audio["features_ms"] * 1e-3), 1), "f64_gflop_per_call": round(audio["windows"] * 4001 * 8000 * 4 / 1e9, 2)}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(clip, meta, min(args.cpu_frames, n), max(1, min(args.cpu_procs, os.cpu_count() or 1)))
         else:

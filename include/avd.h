@@ -138,6 +138,26 @@ int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* 
 int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
                         int64_t frame_stride, float* tokens, int tokens_mem, int timing_reps, float* gemm_ms);
 
+/* Audio analyzer: the per-window loop of reference app/analyzers/audio.py:40-61 for every window of a
+ * mono float32 waveform at once.  wav: n samples (host or device); win: samples per window (the reference uses
+ * int(sr * 0.5) = 8000 at 16 kHz; at most 8192); windows: host array of ceil(n / win) records, filled in order (the
+ * last window may be shorter).  From a record the reference's per-window values follow as
+ *   rms = sqrt(sumsq / length); zcr = float32(zero_cross) / float32(length - 1) / 2;
+ *   flatness = exp(sum_log / nbins) / (sum_mag / nbins); rolloff = rolloff_index / max(1, nbins);
+ *   centroid = sum_fmag / sum_mag          (mag = |rfft(seg * hanning)| + 1e-9, all sums in double)
+ * and the scalar tail (audio.py:63-110) is host numpy (avd_hip/audio.py). */
+typedef struct avd_audio_window {
+    double sumsq;            /* sum of seg^2                                             (audio.py:44) */
+    double sum_log;          /* sum of log(mag)                                          (audio.py:50) */
+    double sum_mag;          /* sum of mag                                               (audio.py:50,51,61) */
+    double sum_fmag;         /* sum of linspace(0,1,nbins) * mag                         (audio.py:60-61) */
+    int32_t zero_cross;      /* sum of |diff(sign(seg))|                                 (audio.py:45) */
+    int32_t length;          /* samples in this window */
+    int32_t rolloff_index;   /* first k with running sum >= 0.85 * sum_mag, else 0       (audio.py:51-58) */
+    int32_t nbins;           /* length / 2 + 1 */
+} avd_audio_window;          /* 48 bytes */
+int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows);
+
 /* Stream ordering for AVD_MEM_DEVICE inputs.  A context launches on its own non-blocking stream, so device memory
  * that another stream is still writing (e.g. torch's current stream: a freshly computed tensor, a .contiguous()
  * copy, a decoder's colour-conversion kernel) must be ordered explicitly: everything enqueued on `producer_stream`
