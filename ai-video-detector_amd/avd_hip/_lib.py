@@ -111,7 +111,7 @@ def load() -> C.CDLL:
     L.avd_analyze_frames_nv12.argtypes = nv12 + [vp]
     L.avd_analyze_frames_nv12_async.argtypes = nv12 + [vp]
     L.avd_vit_set_weights.argtypes = [vp, vp, vp]
-    L.avd_vit_patch_embed.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.c_int,
+    L.avd_vit_patch_embed.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float)]
     L.avd_audio_features.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int]
     L.avd_synchronize.argtypes = [vp]
@@ -294,21 +294,25 @@ class Context:
         b = None if bias is None else np.ascontiguousarray(bias, np.float32).reshape(768)
         self._check(self._L.avd_vit_set_weights(self._h, wbits.ctypes.data, None if b is None else b.ctypes.data))
 
-    def vit_patch_embed(self, frames, timing_reps: int = 0, out=None):
-        """-> (tokens float32[N,196,768], gemm_ms or None).  ``out``: optional torch-ROCm float32 tensor [N,196,768]
-        to receive the tokens in HBM (nothing is copied to the host then)."""
+    def vit_patch_embed(self, frames, timing_reps: int = 0, out=None, bf16: bool = False):
+        """-> (tokens [N,196,768], gemm_ms or None).  Tokens are float32, or with ``bf16=True`` bf16 (returned to the host
+        as float32 after widening).  ``out``: optional contiguous torch-ROCm tensor [N,196,768] (float32, or bfloat16 with
+        ``bf16=True``) that receives the tokens in HBM (nothing is copied to the host then)."""
         ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
         ms = C.c_float(0.0)
         if out is not None:
+            want = "torch.bfloat16" if bf16 else "torch.float32"
             if not (_is_torch_tensor(out) and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (n, 196, 768)
-                    and str(out.dtype) == "torch.float32"):
-                raise ValueError("out must be a contiguous float32 cuda tensor [N,196,768]")
+                    and str(out.dtype) == want):
+                raise ValueError(f"out must be a contiguous {want} cuda tensor [N,196,768]")
             self._after_torch_stream(out)
             tptr, tmem, tokens = out.data_ptr(), AVD_MEM_DEVICE, out
         else:
-            tokens = np.empty((n, 196, 768), np.float32)
+            tokens = np.empty((n, 196, 768), np.uint16 if bf16 else np.float32)
             tptr, tmem = tokens.ctypes.data, AVD_MEM_HOST
-        self._check(self._L.avd_vit_patch_embed(self._h, ptr, mem, n, h, w, rs, fs, tptr, tmem, int(timing_reps), C.byref(ms)))
+        self._check(self._L.avd_vit_patch_embed(self._h, ptr, mem, n, h, w, rs, fs, tptr, tmem, int(bool(bf16)), int(timing_reps), C.byref(ms)))
+        if out is None and bf16:
+            tokens = bf16_bits_to_f32(tokens)
         return tokens, (float(ms.value) if timing_reps > 0 else None)
 
     # -- audio analyzer (reference app/analyzers/audio.py:40-61 for all windows at once) -----------------------

@@ -627,7 +627,7 @@ static int impl_vit_set_weights(avd_ctx* ctx, const uint16_t* w_bf16, const floa
 }
 
 static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
-                                int64_t frame_stride, float* tokens, int tokens_mem, int reps, float* gemm_ms)
+                                int64_t frame_stride, void* tokens, int tokens_mem, int tokens_bf16, int reps, float* gemm_ms)
 {
     if (!ctx) return AVD_ERR_ARG;
     if ((!bgr || !tokens) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
@@ -638,11 +638,14 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     Workspace& ws = ctx->ws;
     if (!ws.d_vit_w) { ctx->err = "avd_vit_set_weights has not been called"; return AVD_ERR_ARG; }
     const size_t m = (size_t)n * 196;
-    if (ws.vit_patch_elems < m * 768) {
-        if (int e = dev_alloc(ctx, ws.d_vit_patches, m * 768)) return e;
-        ws.vit_patch_elems = m * 768;
+    const size_t m_pad = (m + 255) / 256 * 256;           // the persistent GEMM reads whole 256-row tiles of A
+    if (ws.vit_patch_elems < m_pad * 768) {
+        if (int e = dev_alloc(ctx, ws.d_vit_patches, m_pad * 768)) return e;
+        HIP_TRY(ctx, hipMemsetAsync(ws.d_vit_patches, 0, m_pad * 768 * sizeof(uint16_t), ctx->stream));
+        ws.vit_patch_elems = m_pad * 768;
     }
-    float* d_tok = tokens;
+    void* d_tok = tokens;
+    const size_t esz = tokens_bf16 ? sizeof(uint16_t) : sizeof(float);
     if (tokens_mem == AVD_MEM_HOST) {
         if (ws.vit_token_elems < m * 768) {
             if (int e = dev_alloc(ctx, ws.d_vit_tokens, m * 768)) return e;
@@ -654,12 +657,12 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
     if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
     const float* d_bias = ws.vit_has_bias ? ws.d_vit_bias : nullptr;
-    if (int e = launch_vit_patch_embed(ctx, d_bgr, n, h, w, row_stride, frame_stride, ws.d_vit_w, d_bias, d_tok, ws.d_vit_patches)) return e;
+    if (int e = launch_vit_patch_embed(ctx, d_bgr, n, h, w, row_stride, frame_stride, ws.d_vit_w, d_bias, d_tok, tokens_bf16, ws.d_vit_patches)) return e;
     if (reps > 0 && gemm_ms) {
         // the GEMM alone, `reps` launches between two events on the context's stream (the patches stay resident)
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (int r = 0; r < reps; r++)
-            if (int e = launch_gemm_bf16_nt(ctx, ws.d_vit_patches, ws.d_vit_w, d_bias, d_tok, (int)m, 768, 768)) return e;
+            if (int e = launch_gemm_bf16_nt(ctx, ws.d_vit_patches, ws.d_vit_w, d_bias, d_tok, tokens_bf16, (int)m, 768, 768)) return e;
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
         float ms = 0.f;
@@ -667,7 +670,7 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
         *gemm_ms = ms / reps;
     }
     if (tokens_mem == AVD_MEM_HOST)
-        HIP_TRY(ctx, hipMemcpyAsync(tokens, d_tok, sizeof(float) * m * 768, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(tokens, d_tok, esz * m * 768, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return AVD_OK;
 }
@@ -786,9 +789,9 @@ int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* 
 }
 
 int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
-                        float* tokens, int tokens_mem, int timing_reps, float* gemm_ms)
+                        void* tokens, int tokens_mem, int tokens_bf16, int timing_reps, float* gemm_ms)
 {
-    return guarded(ctx, [&] { return impl_vit_patch_embed(ctx, bgr, mem, n, h, w, row_stride, frame_stride, tokens, tokens_mem, timing_reps, gemm_ms); });
+    return guarded(ctx, [&] { return impl_vit_patch_embed(ctx, bgr, mem, n, h, w, row_stride, frame_stride, tokens, tokens_mem, tokens_bf16, timing_reps, gemm_ms); });
 }
 
 int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows)

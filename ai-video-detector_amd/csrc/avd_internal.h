@@ -156,8 +156,9 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
 int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);
 // avd_vit.hip (extension): patchify + bf16 MFMA GEMM; all pointers device
 int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
-                           const uint16_t* d_wt, const float* d_bias, float* d_tokens, uint16_t* d_patches);
-int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, float* d_c, int M, int N, int K);
+                           const uint16_t* d_wt, const float* d_bias, void* d_tokens, int tokens_bf16, uint16_t* d_patches);
+int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, void* d_c, int out_bf16,
+                        int M, int N, int K);
 // avd_audio.hip: per-window features of a mono float32 waveform (device pointers)
 int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, avd_audio_window* d_out, int nwin);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair

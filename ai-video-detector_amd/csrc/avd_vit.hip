@@ -140,12 +140,14 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt(const uint16_t* __restrict
     // LDS-DMAs.  A half stage's LDS slot is free as soon as every wave holds its fragments, i.e. at the next barrier.
     // A wave issues 4 LDS-DMA instructions per half stage: vmcnt(4 * y) = "all but the y youngest half stages landed".
     auto wait_landed = [&](int hs, int issued_last) __attribute__((always_inline)) {      // hs must be readable afterwards
+        __builtin_amdgcn_sched_barrier(0);
         const int younger = issued_last - hs;                // half stages issued after hs (a wave: 4 instructions each)
         if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);                   // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
     };
     auto load_frags = [&](bf16x8 (&a)[8], bf16x8 (&b)[4], int hs) __attribute__((always_inline)) {
         const char* cur = lds + (hs % kStages) * kStage;
@@ -222,41 +224,196 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt(const uint16_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of the same GEMM: one workgroup per CU walks a list of tiles and NEVER drains its pipeline.
+//  * the half-stage stream is continuous across tiles: during the last four steps of a tile the LDS-DMAs of the next
+//    tile's first half stages are already issued -- no prologue latency, no drained ring behind the epilogue;
+//  * the product is formed TRANSPOSED (mfma(b, a): the accumulator tile has n on its rows and m on the lane), so a lane
+//    holds four consecutive COLUMNS of one output row: the epilogue is 32 plain 16-byte (f32) / 8-byte (bf16) stores
+//    per wave straight from the accumulators, no LDS staging, and the ring stays free for the next tile;
+//  * loads and stores of a wave share one in-order vmcnt: the waits of the three steps after an epilogue allow the 32
+//    stores to be outstanding (vmcnt(8 + 32)) -- the half stages they wait for were issued BEFORE the stores; from the
+//    fourth step on the stores are older than what is waited for and have long completed;
+//  * the bias sits in LDS (3 KiB) so that the epilogue issues no loads.
+// Tile order: logical workgroup id = (blockIdx % 8) * (grid / 8) + blockIdx / 8 and tile = id + i * grid: the three
+// 256-column tiles of a 256-row block of A run at the same time on one XCD.
+// ---------------------------------------------------------------------------------------------------------------
+template <int K, int OUT_BF16>
+__global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bt,
+                                                                const float* __restrict__ bias, void* __restrict__ Cv, int M, int N)
+{
+    extern __shared__ __align__(16) char lds[];            // ring of kStages half stages [A | B], then the bias (N floats)
+    constexpr int NH = K / BKH;
+    static_assert(NH >= kStages + 1 && kStages == 4, "the vmcnt immediates below assume a ring of four");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, total = tiles_m * tiles_n;
+    const int lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (lw >= total) return;
+    float* lbias = reinterpret_cast<float*>(lds + kGemmLds);
+    for (int i = threadIdx.x; i < N; i += 512) lbias[i] = bias ? bias[i] : 0.f;
+
+    f32x4 acc[8][4];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // LDS-DMA addressing: a uniform tile pointer (scalar registers) + a per-lane 32-bit byte offset that is the same
+    // for every tile, half stage and operand: row (2 * wave + i) * 16 + lane / 4 of the tile, swizzled chunk.  A is padded
+    // to whole tiles by the caller, so no row needs clamping.
+    unsigned voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (wave * 2 + i) * 16 + (lane >> 2);
+        voff[i] = (unsigned)(r * K + (((lane & 3) ^ swz((r >> 2) & 3)) << 3)) * 2u;
+    }
+    auto issue = [&](int m0, int n0, int hs, int slot) __attribute__((always_inline)) {
+        char* st = lds + slot * kStage;
+        const char* pa = reinterpret_cast<const char*>(A + (int64_t)m0 * K + hs * BKH);
+        const char* pb = reinterpret_cast<const char*>(Bt + (int64_t)n0 * K + hs * BKH);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + voff[i]),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + voff[i]),
+                                             (__attribute__((address_space(3))) void*)(st + kHalfTile + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+    // the product is formed transposed: rows of a 16x16 result = n (B fragment as the first operand), lane column = m
+    auto store_tile = [&](int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;          // four consecutive columns of this lane
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + col);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int row = m0 + wm * 128 + i * 16 + (lane & 15);
+                const f32x4 v = acc[i][j] + bv;
+                if (row < M) {
+                    if (OUT_BF16) {
+                        uint2 pk;
+                        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(Cv) + (int64_t)row * N + col) = pk;
+                    } else {
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(Cv) + (int64_t)row * N + col) = v;
+                    }
+                }
+            }
+        }
+    };
+
+    int tile = lw;
+    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    // prologue of the first tile only: three half stages in flight
+#pragma unroll
+    for (int hs = 0; hs < kStages - 1; hs++) issue(m0, n0, hs, hs);
+    zero_acc();
+    bool first = true;
+    for (;;) {
+        const int nxt = tile + gridDim.x;
+        const bool more = nxt < total;
+        const int m1 = more ? (nxt / tiles_n) * BM : m0, n1 = more ? (nxt % tiles_n) * BN : n0;
+        // Step hs.  A half stage's ring slot is hs mod 4; NH is a multiple of 4, so the next tile's half stage 0 lands in
+        // slot 0 again and the stream of half stages runs on across tiles.
+#pragma unroll
+        for (int hs = 0; hs < NH; hs++) {
+            // half stage hs must have landed.  Younger operations of this wave: the two half stages behind it (8 LDS-DMAs),
+            // plus the 32 stores of the previous tile's epilogue during the first three steps of a later tile (the half
+            // stages waited for there were issued BEFORE those stores).  At the end of the stream there are fewer.
+            __builtin_amdgcn_sched_barrier(0);
+            if (hs < 3 && !first) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            else if (hs == NH - 2 && !more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (hs == NH - 1 && !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // ... for every wave; the same barrier says everyone has finished reading half stage hs - 1, whose slot is
+            // refilled with stream position hs + 3
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);               // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
+        __builtin_amdgcn_sched_barrier(0);                   // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
+            if (hs + kStages - 1 < NH) issue(m0, n0, hs + kStages - 1, (hs + kStages - 1) % kStages);
+            else if (more) issue(m1, n1, hs + kStages - 1 - NH, (hs + kStages - 1) % kStages);
+            // fragments in two halves: the reads of A rows 64..127 are in flight while the first 16 MFMAs run (a single
+            // "read all, wait, multiply" leaves the matrix pipe idle for an LDS round trip per step: both waves of a SIMD
+            // come out of the barrier together)
+            {
+                const char* cur = lds + (hs % kStages) * kStage;
+                const int chunk = lane >> 4, r16 = lane & 15;
+                bf16x8 b[4], alo[4], ahi[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = frag(cur + kHalfTile, wn * 64 + j * 16 + r16, chunk);
+#pragma unroll
+                for (int i = 0; i < 4; i++) alo[i] = frag(cur, wm * 128 + i * 16 + r16, chunk);
+#pragma unroll
+                for (int i = 0; i < 4; i++) ahi[i] = frag(cur, wm * 128 + (i + 4) * 16 + r16, chunk);
+                __builtin_amdgcn_sched_barrier(0);          // all twelve reads are issued before the first MFMA
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], alo[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i + 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], ahi[i], acc[i + 4][j], 0, 0, 0);
+            }
+        }
+        store_tile(m0, n0);
+        if (!more) break;
+        zero_acc();
+        tile = nxt; m0 = m1; n0 = n1;
+        first = false;
+    }
+}
+
 }  // namespace
 
 // tokens[M][768] (device, f32) = patchify(frames) x Wt^T + bias.  d_wt: bf16 [768 out][768 k]; d_bias f32[768] or null.
 int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
-                           const uint16_t* d_wt, const float* d_bias, float* d_tokens, uint16_t* d_patches)
+                           const uint16_t* d_wt, const float* d_bias, void* d_tokens, int tokens_bf16, uint16_t* d_patches)
 {
     if (n <= 0) return 0;
     const int64_t px = (int64_t)n * kSide * kSide;
     hipLaunchKernelGGL(k_vit_patchify, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, n, h, w, row_stride,
                        frame_stride, d_patches);
-    return launch_gemm_bf16_nt(ctx, d_patches, d_wt, d_bias, d_tokens, n * kTokens, kDim, kDim);
+    return launch_gemm_bf16_nt(ctx, d_patches, d_wt, d_bias, d_tokens, tokens_bf16, n * kTokens, kDim, kDim);
 }
 
-int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, float* d_c, int M, int N, int K)
+int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, void* d_c, int out_bf16,
+                        int M, int N, int K)
 {
     if (M <= 0) return 0;
-    if (N % BN || K != kDim) { ctx->err = "gemm_bf16_nt: N must be a multiple of 256 and K = 768"; return AVD_ERR_ARG; }
+    if (N % BN || K != kDim || N > 4096) { ctx->err = "gemm_bf16_nt: N must be a multiple of 256 (<= 4096) and K = 768"; return AVD_ERR_ARG; }
     static const int dbg = [] { const char* e = std::getenv("AVD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();   // timing experiments only
+    static const int variant = [] { const char* e = std::getenv("AVD_GEMM_VARIANT"); return e ? std::atoi(e) : 0; }();   // f32 tokens: 0 = one tile per workgroup (measured faster), 1 = persistent
     const int total = ((M + BM - 1) / BM) * (N / BN);
-    const int grid = (total + 7) / 8 * 8;
-    auto go = [&](auto kern) -> int {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kGemmLds, ctx->stream, d_a, d_bt, d_bias, d_c, M, N);
+    auto go = [&](auto kern, int grid, size_t lds, auto... args) -> int {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, args...);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
+    if (variant == 1 || out_bf16) {
+        // one workgroup per CU (LDS: ring + bias), grid a multiple of 8 so that the XCD-aware order is a bijection
+        int grid = ctx->num_cus / 8 * 8;
+        if (grid < 8) grid = 8;
+        if (grid > (total + 7) / 8 * 8) grid = (total + 7) / 8 * 8;
+        const size_t lds = kGemmLds + (size_t)N * sizeof(float);
+        if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1>, grid, lds, d_a, d_bt, d_bias, d_c, M, N);
+        return go(k_gemm_bf16_nt_persistent<kDim, 0>, grid, lds, d_a, d_bt, d_bias, d_c, M, N);
+    }
+    const int grid = (total + 7) / 8 * 8;
+    float* c32 = static_cast<float*>(d_c);
     switch (dbg) {
 #ifdef AVD_GEMM_DEBUG
-    case 1: return go(k_gemm_bf16_nt<kDim, 1>);
-    case 2: return go(k_gemm_bf16_nt<kDim, 2>);
-    case 4: return go(k_gemm_bf16_nt<kDim, 4>);
-    case 5: return go(k_gemm_bf16_nt<kDim, 5>);
-    case 6: return go(k_gemm_bf16_nt<kDim, 6>);
-    case 7: return go(k_gemm_bf16_nt<kDim, 7>);
+    case 1: return go(k_gemm_bf16_nt<kDim, 1>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+    case 2: return go(k_gemm_bf16_nt<kDim, 2>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+    case 4: return go(k_gemm_bf16_nt<kDim, 4>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+    case 5: return go(k_gemm_bf16_nt<kDim, 5>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+    case 6: return go(k_gemm_bf16_nt<kDim, 6>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+    case 7: return go(k_gemm_bf16_nt<kDim, 7>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
 #endif
-    default: return go(k_gemm_bf16_nt<kDim, 0>);
+    default: return go(k_gemm_bf16_nt<kDim, 0>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
     }
 }

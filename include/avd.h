@@ -132,11 +132,12 @@ int avd_analyze_frames_nv12_async(avd_ctx* ctx, const uint8_t* y, const uint8_t*
  * layout of a [768][3][16][16] conv weight, channels RGB), bias float[768] or NULL; both host pointers, copied.
  * avd_vit_patch_embed: each BGR frame is resized to 224x224 (bilinear), normalised ((x/255 - mean)/std, ImageNet
  * constants), cut into 196 patches of 16x16x3, rounded to bf16 and multiplied with the weights (f32 accumulation):
- * tokens float[n][196][768], host or device (tokens_mem).  If timing_reps > 0 and gemm_ms != NULL the GEMM kernel alone
- * is launched timing_reps more times between two HIP events and its mean duration is returned (bench hook). */
+ * tokens [n][196][768], float (tokens_bf16 = 0) or bf16 bit patterns (tokens_bf16 = 1, round to nearest even), host or
+ * device (tokens_mem).  If timing_reps > 0 and gemm_ms != NULL the GEMM kernel alone is launched timing_reps more times
+ * between two HIP events and its mean duration is returned (bench hook). */
 int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* bias);
 int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
-                        int64_t frame_stride, float* tokens, int tokens_mem, int timing_reps, float* gemm_ms);
+                        int64_t frame_stride, void* tokens, int tokens_mem, int tokens_bf16, int timing_reps, float* gemm_ms);
 
 /* Audio analyzer: the per-window loop of reference app/analyzers/audio.py:40-61 for every window of a
  * mono float32 waveform at once.  wav: n samples (host or device); win: samples per window (the reference uses

@@ -79,6 +79,9 @@ def test_patch_embed_against_numpy(ctx, n, h, w):
     got = tokens.reshape(-1, 768).astype(np.float64)
     err = np.abs(got - ref)
     assert np.all(err <= 1e-3 + 1e-3 * np.abs(ref)), (err.max(), np.abs(ref).max())
+    # bf16 tokens: the same product rounded once to bf16 (nearest even): within half a bf16 ulp of the f32 result
+    tok16, _ = ctx.vit_patch_embed(frames, bf16=True)
+    assert np.all(np.abs(tok16.reshape(-1, 768).astype(np.float64) - got) <= np.abs(got) * 2.0 ** -8 + 1e-30)
     # asymmetric check of the fragment / output maps: a one-hot weight row copies one input column to one output column
     onehot = np.zeros((768, 768), np.float32)
     onehot[np.arange(768), (np.arange(768) * 7 + 3) % 768] = 1.0
@@ -98,3 +101,6 @@ def test_patch_embed_device_output_and_rows_not_multiple_of_tile(ctx):
     out = torch.full((7, 196, 768), float("nan"), dtype=torch.float32, device="cuda:0")
     dev, _ = ctx.vit_patch_embed(torch.from_numpy(frames).to("cuda:0"), out=out)
     assert dev is out and np.array_equal(out.cpu().numpy(), host) and np.isfinite(host).all()
+    out16 = torch.zeros((7, 196, 768), dtype=torch.bfloat16, device="cuda:0")
+    ctx.vit_patch_embed(torch.from_numpy(frames).to("cuda:0"), out=out16, bf16=True)
+    assert np.array_equal(out16.float().cpu().numpy(), ctx.vit_patch_embed(frames, bf16=True)[0])
