@@ -26,6 +26,7 @@ EXPORTS = (
     "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
     "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features",
+    "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
@@ -114,6 +115,9 @@ def load() -> C.CDLL:
     L.avd_vit_patch_embed.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float)]
     L.avd_audio_features.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int]
+    L.avd_comm_unique_id.argtypes = [vp]
+    L.avd_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.avd_allgather_records.argtypes = [vp, vp, C.c_int, vp]
     L.avd_synchronize.argtypes = [vp]
     L.avd_wait_stream.argtypes = [vp, vp]
     L.avd_release_workspace.argtypes = [vp]
@@ -333,6 +337,27 @@ class Context:
         nwin = (n + win - 1) // win if n else 0
         out = np.zeros(nwin, AUDIO_WINDOW_DTYPE)
         self._check(self._L.avd_audio_features(self._h, ptr, mem, n, int(win), out.ctypes.data, nwin))
+        return out
+
+    # -- record exchange across ranks (RCCL, bound at run time) --------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = load().avd_comm_unique_id(buf)
+        if rc != 0:
+            raise AvdError(f"avd_comm_unique_id failed with status {rc} (is librccl.so available?)")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._check(self._L.avd_comm_init(self._h, int(rank), int(world), C.create_string_buffer(unique_id, 128)))
+        self._comm_world = int(world)
+
+    def allgather_records(self, local: np.ndarray) -> np.ndarray:
+        local = np.ascontiguousarray(local)
+        assert local.dtype == RECORD_DTYPE
+        out = np.zeros(len(local) * getattr(self, "_comm_world", 1), RECORD_DTYPE)
+        self._check(self._L.avd_allgather_records(self._h, local.ctypes.data, len(local), out.ctypes.data))
         return out
 
     def analyze_frames_async(self, frames, rec: np.ndarray):

@@ -304,6 +304,7 @@ static void impl_destroy(avd_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_destroy(ctx);
     free_ws(ctx->ws);
     if (ctx->d_fbc) (void)hipFree(ctx->d_fbc);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -797,6 +798,22 @@ int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h,
 int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows)
 {
     return guarded(ctx, [&] { return impl_audio_features(ctx, wav, mem, n, win, windows, max_windows); });
+}
+
+int avd_comm_unique_id(void* id128)
+{
+    if (!id128) return AVD_ERR_ARG;
+    return guarded(nullptr, [&] { std::string err; return comm_unique_id(err, id128); });
+}
+int avd_comm_init(avd_ctx* ctx, int rank, int world, const void* id128)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    return guarded(ctx, [&] { return comm_init(ctx, rank, world, id128); });
+}
+int avd_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count, avd_frame_record* all)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    return guarded(ctx, [&] { return comm_allgather_records(ctx, local, count, all); });
 }
 
 int avd_wait_stream(avd_ctx* ctx, void* producer_stream) { return guarded(ctx, [&] { return impl_wait_stream(ctx, producer_stream); }); }

@@ -140,6 +140,9 @@ struct avd_ctx {
     FbConsts fbc;
     void* d_fbc = nullptr;          // FbConsts on device
     int last_n = 0;
+    void* comm = nullptr;            // RCCL communicator (avd_comm.cpp), bound at run time
+    int comm_rank = 0, comm_world = 1;
+    void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
 };
 
@@ -159,6 +162,11 @@ int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int
                            const uint16_t* d_wt, const float* d_bias, void* d_tokens, int tokens_bf16, uint16_t* d_patches);
 int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, void* d_c, int out_bf16,
                         int M, int N, int K);
+// avd_comm.cpp: RCCL all-gather of the per-frame records (dlopen, no link-time dependency)
+int comm_unique_id(std::string& err, void* id128);
+int comm_init(avd_ctx* ctx, int rank, int world, const void* id128);
+void comm_destroy(avd_ctx* ctx);
+int comm_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count, avd_frame_record* all);
 // avd_audio.hip: per-window features of a mono float32 waveform (device pointers)
 int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, avd_audio_window* d_out, int nwin);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair

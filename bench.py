@@ -187,6 +187,9 @@ def main():
                          "per-pair workgroups of one clip's Farneback levels (119 of 256 CUs), the records all-gather, the host "
                          "tail and the launch gaps of one clip overlap with the kernels of another; 1 = every step is submitted "
                          "and drained alone.  All K steps complete inside the timed region either way.")
+    ap.add_argument("--collective", default="torch", choices=["torch", "native"],
+                    help="record all-gather for N>1: torch.distributed (default) or the library's own avd_allgather_records "
+                         "(RCCL bound at run time inside libavd_hip.so; the unique id travels through torch's process group)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
@@ -235,6 +238,11 @@ def main():
     for c in ctxs:
         c.set_profiling(True)
     recs = [np.zeros(n, avd_hip.RECORD_DTYPE) for _ in range(m)]
+    if use_dist and args.collective == "native":
+        for c in ctxs:                                      # one communicator per context (each has its own stream)
+            box = [avd_hip.Context.comm_unique_id() if rank == 0 else None]
+            tdist.broadcast_object_list(box, src=0)
+            c.comm_init(rank, world, box[0])
     hints = heuristics_v2.compute_hints({**meta, "bit_rate": 8_000_000}, "")
     stage = np.zeros(6)
     pending = []
@@ -249,7 +257,10 @@ def main():
         ctxs[j].synchronize()
         stage[:] += np.array(ctxs[j].stage_ms())
         rec = recs[j]
-        allrec = avd_dist.gather_fixed(rec, device=gather_dev) if use_dist else rec
+        if use_dist and args.collective == "native":
+            allrec = ctxs[j].allgather_records(rec)
+        else:
+            allrec = avd_dist.gather_fixed(rec, device=gather_dev) if use_dist else rec
         # scalar tail (video.py:54-83) + fusion (fusion.py:16) for this rank's clip; other clips' records are local too
         video = records_to_result(allrec[rank * n:(rank + 1) * n], h * w, w, h, meta["fps"], meta["duration"])
         fused = fusion.fuse(audio_unavailable("", meta), video, hints)

@@ -159,6 +159,17 @@ typedef struct avd_audio_window {
 } avd_audio_window;          /* 48 bytes */
 int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows);
 
+/* The one exchange step of the path: frames and clips shard across GPUs with no data-path collective;
+ * only the 32-byte records are reassembled, with ONE RCCL all-gather over xGMI per batch (a few KB: latency-bound).
+ * RCCL is bound at run time (dlopen), so single-GPU use never loads it.  avd_comm_unique_id: one rank creates the
+ * 128-byte id and the caller distributes it (file, environment, torch's store ...); avd_comm_init: every rank, with
+ * its own context (one process per GPU); avd_allgather_records: every rank passes `count` records (the same count on
+ * every rank: whole clips per rank, or shards padded by the caller) and receives world * count in rank order.
+ * Host pointers; the call blocks until the gathered records are in `all`. */
+int avd_comm_unique_id(void* id128);
+int avd_comm_init(avd_ctx* ctx, int rank, int world, const void* id128);
+int avd_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count, avd_frame_record* all);
+
 /* Stream ordering for AVD_MEM_DEVICE inputs.  A context launches on its own non-blocking stream, so device memory
  * that another stream is still writing (e.g. torch's current stream: a freshly computed tensor, a .contiguous()
  * copy, a decoder's colour-conversion kernel) must be ordered explicitly: everything enqueued on `producer_stream`

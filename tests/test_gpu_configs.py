@@ -201,3 +201,23 @@ def test_cfg2_whole_clip_sharding_two_ranks(tmp_path, ctx, oracle):
         _assert_records_equal(single[k:k + CFG2_FRAMES], _oracle_records(oracle, _cfg2_clip(r, j)), f"rank {r} clip {j}")
     # each clip's first frame starts a new clip: no Hamming / flow carried over from the previous clip
     assert np.all(single["ham"][::CFG2_FRAMES] == -1) and np.all(single["flow_mean"][::CFG2_FRAMES] == 0)
+
+
+def test_native_rccl_allgather_of_records(ctx):
+    """avd_allgather_records: RCCL bound at run time.  A 1-GPU lease can only form a communicator of one
+    rank (two ranks on one device are refused by RCCL as duplicate GPUs): the entry points, the staging and the
+    collective call itself run; rank order with more ranks is covered by the gloo tests of the same layout."""
+    import avd_hip
+    from avd_hip import synth
+    rec = ctx.analyze_frames(synth.make_clip(5, 96, 160, seed=77, dup_every=2))
+    with avd_hip.Context(0) as c:
+        with pytest.raises(avd_hip.AvdError):
+            c.allgather_records(rec)                                    # no communicator yet
+        uid = avd_hip.Context.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        c.comm_init(0, 1, uid)
+        got = c.allgather_records(rec)
+        assert np.array_equal(got, rec)
+        assert np.array_equal(c.allgather_records(rec[:2]), rec[:2])    # another size re-uses the communicator
+        with pytest.raises(avd_hip.AvdError):
+            c.comm_init(3, 2, uid)                                      # rank out of range
