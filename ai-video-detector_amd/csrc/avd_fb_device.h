@@ -116,6 +116,65 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
     M[3] = r4 * r2 + r6 * r3;
     M[4] = r6 * r2 + r5 * r3;
 }
+// ---- leaner forms for the fused level kernel (avd_fbfused.hip): same arithmetic, fewer instructions per row ----------
+// * the warped integer position is computed once (in the gather step) and carried to the finish step;
+// * the 5-pixel border attenuation (x < 5 ? b[x] : 1) * (x >= w-5 ? b[w-x-1] : 1) * (y < 5 ? ...) * (y >= h-5 ? ...) is split
+//   into a per-lane factor sx (constant for the whole kernel) and a per-row factor sy (wave-uniform).  For images of at
+//   least 10 pixels at most one x factor and one y factor differ from 1, so cv2's left-to-right product equals sx * sy
+//   bit for bit (multiplications by 1.0f are exact), and interior pixels multiply by exactly 1.
+struct NeG2 { float top[10], bot[10]; int x1, y1; };
 
+__device__ __forceinline__ float border_factor(int p, int len)
+{
+    const float lo = p < 2 ? 0.14f : 0.4472f, hi = len - p - 1 < 2 ? 0.14f : 0.4472f;
+    return (p < 5 ? lo : 1.f) * (p >= len - 5 ? hi : 1.f);
+}
+
+__device__ __forceinline__ void ne_gather2(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
+                                           int w, int h, NeG2& g)
+{
+    const float fx = x + in.dx, fy = y + in.dy;
+    g.x1 = floor_f(fx); g.y1 = floor_f(fy);
+    const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
+    const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
+    const F4 t0 = ld_off<F4>(R, pb), t1 = ld_off<F4>(R, pb + 16u);
+    const F2 t2 = ld_off<F2>(R, pb + 32u);
+    const F4 b0 = ld_off<F4>(R, qb), b1 = ld_off<F4>(R, qb + 16u);
+    const F2 b2 = ld_off<F2>(R, qb + 32u);
+    g.top[0] = t0.a; g.top[1] = t0.b; g.top[2] = t0.c; g.top[3] = t0.d; g.top[4] = t1.a;
+    g.top[5] = t1.b; g.top[6] = t1.c; g.top[7] = t1.d; g.top[8] = t2.a; g.top[9] = t2.b;
+    g.bot[0] = b0.a; g.bot[1] = b0.b; g.bot[2] = b0.c; g.bot[3] = b0.d; g.bot[4] = b1.a;
+    g.bot[5] = b1.b; g.bot[6] = b1.c; g.bot[7] = b1.d; g.bot[8] = b2.a; g.bot[9] = b2.b;
+}
+
+__device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x, int y, int w, int h, float sx, float sy,
+                                           float (&M)[5])
+{
+    const float dx = in.dx, dy = in.dy;
+    const int x1 = g.x1, y1 = g.y1;
+    const float fx = (x + dx) - x1, fy = (y + dy) - y1;
+    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const float b2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
+    const float b3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
+    const float b4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
+    const float b5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
+    const float b6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
+    float r2 = inside ? b2 : 0.f, r3 = inside ? b3 : 0.f;
+    float r4 = inside ? (in.r0[2] + b4) * 0.5f : in.r0[2];
+    float r5 = inside ? (in.r0[3] + b5) * 0.5f : in.r0[3];
+    float r6 = inside ? (in.r0[4] + b6) * 0.25f : in.r0[4] * 0.5f;
+    r2 = (in.r0[0] - r2) * 0.5f;
+    r3 = (in.r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    const float scale = sx * sy;
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
 
 }  // namespace

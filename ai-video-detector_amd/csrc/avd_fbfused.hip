@@ -106,22 +106,26 @@ __device__ __forceinline__ void role_vertical(const float* __restrict__ R, const
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
 
     NeIn in[4];
-    NeG g[2];
+    NeG2 g[2];
+    const float sx = border_factor(x, W);                 // x part of the border attenuation: a per-lane constant
     float ring[16][5];                                  // ring[e & 15] = normal-equation row of entry e
     double vs[5] = {0., 0., 0., 0., 0.};
     unsigned goff = 0;                                  // group buffer being filled (offset in doubles)
 #pragma unroll
     for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
-    ne_gather(R, r1base, in[0], x, row_of(0), W, H, plane, g[0]);
+    ne_gather2(R, r1base, in[0], x, row_of(0), W, H, g[0]);
 
     // one entry: evaluate, refill the prefetch slots, update the running sums, publish the vsum row
     auto step = [&](int e, int kk, bool first, bool refill_g, bool refill_in) __attribute__((always_inline)) {
-        float a[5];
-        ne_finish(in[kk & 3], g[kk & 1], x, row_of(e), W, H, a);
-        // the refills must stay below the arithmetic that consumes the old contents of their slots (see k_uv)
-        __builtin_amdgcn_sched_barrier(0);
-        if (refill_g && !(dbg & 4)) ne_gather(R, r1base, in[(kk + 1) & 3], x, row_of(e + 1), W, H, plane, g[(kk + 1) & 1]);
+        // Refills FIRST: the gather of the next entry goes into the slot the previous entry released (this entry's is
+        // the other one) and the inputs three entries ahead into the slot of entry e - 1, so nothing this entry still
+        // needs is overwritten -- and the gather gets a whole row of lead instead of the tail of one (issued after the
+        // arithmetic it had ~300 cycles before its use at the top of the next step: less than an L2 round trip).
+        if (refill_g && !(dbg & 4)) ne_gather2(R, r1base, in[(kk + 1) & 3], x, row_of(e + 1), W, H, g[(kk + 1) & 1]);
         if (refill_in && !(dbg & 4)) ne_load(R, flow, r0base, flbase, x, row_of(e + 3), W, plane, in[(kk + 3) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        float a[5];
+        ne_finish2(in[kk & 3], g[kk & 1], x, row_of(e), W, H, sx, border_factor(row_of(e), H), a);
         if (first && kk == 0) {
 #pragma unroll
             for (int c = 0; c < 5; c++) vs[c] = (double)(a[c] * (float)(kM + 2));
@@ -313,7 +317,8 @@ __device__ __forceinline__ void role_solve(const float* __restrict__ R, const do
         for (int i = 0; i < RL + FL; i++) asm volatile("" ::"v"(tv[par][i]));
     };
     auto touch_issue = [&](int j, int par) __attribute__((always_inline)) {
-        // V is filling group j + 1 now; rows [y0, y0 + G) enter its box filter PF_ROWS rows later
+        // V is filling group j + 1 now; rows [y0, y0 + G) enter its box filter PF_ROWS rows later.  Plain loads on purpose:
+        // as non-temporal loads (no L1 allocation, streaming hint) the level kernel took 0.95 instead of 0.87 ms
         const int y0 = G * (j + 1) + kM + PF_ROWS;
         if (y0 >= H || (dbg & 8)) return;
         const int rows = y0 + G <= H ? G : H - y0;
@@ -406,6 +411,10 @@ __global__ __launch_bounds__((64 * Geo<W, K, G>::NWAVES)) void k_fb_level(const 
     const int smap = Ge::NWAVES > 3 ? 3 : Ge::NVW;          // scanner's wave
     const int ridx = wave < smap ? wave : wave - 1;        // index among the non-scanner waves
     if (wave != smap && ridx < Ge::NVW) {
+        // two SIMDs carry two V waves each (waves w and w + 4); issue arbitration favours the OLDER wave, so the younger
+        // one of a pair would be the pole of every barrier interval (barrier-wait stamps: 7 % vs 20-27 % of its partner):
+        // a static priority for the younger ones evens the pair out
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
         for (int it = 0; it < iterations; it++) {
             // flow rows cached in this CU's L1 during the previous iteration are stale now
             if (it > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -445,8 +454,7 @@ int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, flo
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();
     switch (w) {
     case 320:
-        if (var == 1) launch_one<320, 2, 2>(stream, grid, R, flow, np, iterations, dbg);
-        else if (var == 2) launch_one<320, 1, 4>(stream, grid, R, flow, np, iterations, dbg);
+        if (var == 1) launch_one<320, 2, 2>(stream, grid, R, flow, np, iterations, dbg);      // A/B: two segments (slower)
         else launch_one<320, 4, 2>(stream, grid, R, flow, np, iterations, dbg);
         break;
     case 160: launch_one<160, 2, 4>(stream, grid, R, flow, np, iterations, dbg); break;
