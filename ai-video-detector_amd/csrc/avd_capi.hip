@@ -620,7 +620,10 @@ static int impl_vit_set_weights(avd_ctx* ctx, const uint16_t* w_bf16, const floa
     Workspace& ws = ctx->ws;
     if (!ws.d_vit_w) if (int e = dev_alloc(ctx, ws.d_vit_w, (size_t)768 * 768)) return e;
     if (!ws.d_vit_bias) if (int e = dev_alloc(ctx, ws.d_vit_bias, (size_t)768)) return e;
-    HIP_TRY(ctx, hipMemcpyAsync(ws.d_vit_w, w_bf16, sizeof(uint16_t) * 768 * 768, hipMemcpyHostToDevice, ctx->stream));
+    // the GEMM reads its operands in 1-KiB blocks (avd_vit.hip): re-tile the row-major weight once, here
+    std::vector<uint16_t> blocked((size_t)768 * 768);
+    gemm_block_operand(w_bf16, blocked.data(), 768, 768);
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_vit_w, blocked.data(), sizeof(uint16_t) * 768 * 768, hipMemcpyHostToDevice, ctx->stream));
     if (bias) HIP_TRY(ctx, hipMemcpyAsync(ws.d_vit_bias, bias, sizeof(float) * 768, hipMemcpyHostToDevice, ctx->stream));
     ws.vit_has_bias = bias != nullptr;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -639,7 +642,7 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     Workspace& ws = ctx->ws;
     if (!ws.d_vit_w) { ctx->err = "avd_vit_set_weights has not been called"; return AVD_ERR_ARG; }
     const size_t m = (size_t)n * 196;
-    const size_t m_pad = (m + 255) / 256 * 256;           // the persistent GEMM reads whole 256-row tiles of A
+    const size_t m_pad = (m + kGemmRowPad - 1) / kGemmRowPad * kGemmRowPad;   // the persistent GEMM reads whole tiles of A (256 or 384 rows)
     if (ws.vit_patch_elems < m_pad * 768) {
         if (int e = dev_alloc(ctx, ws.d_vit_patches, m_pad * 768)) return e;
         HIP_TRY(ctx, hipMemsetAsync(ws.d_vit_patches, 0, m_pad * 768 * sizeof(uint16_t), ctx->stream));

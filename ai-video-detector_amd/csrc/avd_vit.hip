@@ -8,20 +8,24 @@
 //   k_vit_patchify   BGR uint8 frame -> 224x224 bilinear (float taps, cv2's INTER_LINEAR centre mapping) -> RGB,
 //                    (x/255 - mean)/std -> bf16 (round to nearest even), written as the im2col matrix of a 16x16/16
 //                    convolution: A[frame*196 + patch][c*256 + py*16 + px]  (the order of a [768][3][16][16] conv weight)
-//   k_gemm_bf16_nt   tokens[M][768] = A[M][768] x Wt[768][768]^T + bias, bf16 in, f32 accumulate / out.
+//   k_gemm_bf16_nt   tokens[M][768] = A[M][768] x Wt[768][768]^T + bias, bf16 in, f32 accumulate, f32 or bf16 out.
 //
-// The GEMM: 256x256 output tile per 512-thread workgroup (8 waves as 2 x 4, a wave owns 128x64 = 8x4 MFMA tiles of
-// v_mfma_f32_16x16x32_bf16: 128 accumulator registers).  Both operands are K-contiguous, so one staging routine serves
-// both: global_load_lds_dwordx4 (16 bytes per lane straight into LDS, no VGPR round trip).  The staging unit is a HALF
-// stage, 32 deep in K (256 rows x 64 B per operand, 32 KiB for both): a ring of four of them in 128 KiB of LDS keeps
-// THREE in flight beside the one being read (a 64-deep double buffer would keep one, less than a loaded HBM round trip),
-// with counted vmcnt + a raw s_barrier per half stage (a __syncthreads would drain the LDS-DMAs).  The LDS image is
-// XOR-swizzled (16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3) of its 64-byte row), applied on the SOURCE
-// address since the LDS side of an LDS-DMA is lane-linear; a ds_read_b128 of a fragment (16 rows x one chunk) then
-// touches 16 distinct 16-byte bank groups.  The epilogue goes through LDS so that a store instruction writes whole
-// 256-byte rows.  XCD-aware tile order: the three 256-column tiles of one 256-row block run on the same XCD, so a block
-// of A is fetched from HBM once.
+// OPERAND LAYOUT IN HBM ("blocked"): both GEMM operands are K-contiguous matrices stored as 1-KiB blocks of 16 rows x 32
+// k, block (row / 16, k / 32) at ((row / 16) * (K / 32) + k / 32) * 1 KiB, and INSIDE a block exactly the bytes of the LDS
+// image the MFMA fragments are read from: row r at r * 64, its four 16-byte chunks XOR-swizzled (chunk c in slot
+// c ^ swz((r >> 2) & 3)).  The patchify kernel writes A that way and avd_vit_set_weights re-tiles the row-major weight
+// once on upload, so that one global_load_lds_dwordx4 wave-instruction (16 bytes per lane straight into LDS, no VGPR
+// round trip) copies ONE contiguous, 128-byte-aligned KiB: eight whole cache lines.  With row-major operands the same
+// instruction touched sixteen half lines (64 bytes of each of 16 rows) and the L2 -> LDS path, not the matrix pipe, set
+// the kernel's time (profiles/r02_experiments.md).
+//
+// The GEMM: a 512-thread workgroup per CU walks 256 x 256 (or 384 x 192) output tiles; 8 waves, a wave owns 8 x 4 (6 x 6)
+// MFMA tiles of v_mfma_f32_16x16x32_bf16.  The staging unit is a HALF stage, 32 deep in K (64 B per row, 32 KiB for both
+// operands of a 256 x 256 tile): a ring of four of them in LDS keeps THREE in flight beside the one being read, with
+// counted vmcnt + a raw s_barrier per half stage (a __syncthreads would drain the LDS-DMAs).  A ds_read_b128 of a
+// fragment (16 rows x one chunk) touches 16 distinct 16-byte bank groups thanks to the swizzle.
 #include <cstdlib>
+#include <type_traits>
 #include "avd_internal.h"
 
 namespace {
@@ -36,6 +40,20 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float v)
 {
     const unsigned u = __float_as_uint(v);
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);       // round to nearest even (inputs are finite)
+}
+
+// Bank swizzle of a half tile (64-byte rows, four 16-byte chunks per row, four rows per 256-byte bank row): chunk c of
+// row r sits in slot c ^ swz((r >> 2) & 3).  A ds_read_b128 is served in groups of 16 lanes that are NOT contiguous
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...): with lane = (chunk << 4) | row a group reads rows {0-3, 12-15} of
+// one chunk and rows {4-11} of the next, and swz = {0, 2, 3, 1} is what makes those sixteen accesses hit sixteen
+// different 16-byte bank groups (the plain XOR with (r >> 2) & 3 is two-way conflicted for these groups).
+__host__ __device__ __forceinline__ int swz(int k) { return k ? (k % 3) + 1 : 0; }
+
+// element index of (row, k) in the blocked operand layout (see the head of this file)
+__host__ __device__ __forceinline__ int64_t blocked_index(int row, int k, int K)
+{
+    const int r = row & 15, kk = k & 31;
+    return ((int64_t)(row >> 4) * (K >> 5) + (k >> 5)) * 512 + r * 32 + (((kk >> 3) ^ swz((r >> 2) & 3)) << 3) + (kk & 7);
 }
 
 // one thread = one output pixel (x, y) of one frame, three channels
@@ -60,314 +78,276 @@ __global__ __launch_bounds__(256) void k_vit_patchify(const uint8_t* __restrict_
     const uint8_t *p10 = fr + (int64_t)y1 * row_stride + x0 * 3, *p11 = fr + (int64_t)y1 * row_stride + x1 * 3;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};   // RGB (ImageNet)
     const int patch = (y / kPatch) * kGrid + x / kPatch;
-    uint16_t* out = A + ((int64_t)f * kTokens + patch) * kDim + (y % kPatch) * kPatch + (x % kPatch);
+    const int row = f * kTokens + patch, k0 = (y % kPatch) * kPatch + (x % kPatch);
 #pragma unroll
     for (int c = 0; c < 3; c++) {                       // c = RGB channel index; the frame is BGR
         const int s = 2 - c;
         const float top = p00[s] + (p01[s] - (float)p00[s]) * fx, bot = p10[s] + (p11[s] - (float)p10[s]) * fx;
         const float v = top + (bot - top) * fy;
-        out[c * kPatch * kPatch] = f32_to_bf16((v * (1.f / 255.f) - mean[c]) * istd[c]);
+        A[blocked_index(row, c * kPatch * kPatch + k0, kDim)] = f32_to_bf16((v * (1.f / 255.f) - mean[c]) * istd[c]);
     }
 }
 
-constexpr int BM = 256, BN = 256, BKH = 32;               // a staging unit ("half stage") is 32 deep in K
-constexpr int kHalfTile = BM * BKH * 2;                     // 16 KiB: one operand, 256 rows x 64 B
-constexpr int kStage = 2 * kHalfTile;                       // A half tile | B half tile
+constexpr int BKH = 32;                                     // a staging unit ("half stage") is 32 deep in K
 constexpr int kStages = 4;                                  // ring: kStages - 1 half stages in flight beside the one being read
                                                             // (5 = all 160 KiB of LDS measured no faster than 4)
-constexpr int kGemmLds = kStages * kStage;                  // 128 KiB
-
-// Bank swizzle of a half tile (64-byte rows, four 16-byte chunks per row, four rows per 256-byte bank row): chunk c of
-// row r sits in slot c ^ swz((r >> 2) & 3).  A ds_read_b128 is served in groups of 16 lanes that are NOT contiguous
-// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...): with lane = (chunk << 4) | row a group reads rows {0-3, 12-15} of
-// one chunk and rows {4-11} of the next, and swz = {0, 2, 3, 1} is what makes those sixteen accesses hit sixteen
-// different 16-byte bank groups (the plain XOR with (r >> 2) & 3 is two-way conflicted for these groups).
-__device__ __forceinline__ int swz(int k) { return k ? (k % 3) + 1 : 0; }
-
-// stage one operand half tile (256 rows x 32 k = 64 B per row) into LDS: wave `wave` issues instructions 2*wave and
-// 2*wave+1, each 16 rows.
-__device__ __forceinline__ void stage_half(const uint16_t* __restrict__ src, int row0, int rows_total, int K, int k0,
-                                           char* lds_tile, int wave, int lane)
-{
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int inst = wave * 2 + i;
-        const int r = inst * 16 + (lane >> 2);                         // tile row this lane fills
-        const int chunk = (lane & 3) ^ swz((r >> 2) & 3);              // which 16-byte chunk of the row lands in slot lane & 3
-        int gr = row0 + r;
-        gr = gr < rows_total ? gr : rows_total - 1;                    // rows past the end repeat the last one (never stored)
-        const uint16_t* g = src + (int64_t)gr * K + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lds_tile + inst * 1024), 16, 0, 0);
-    }
-}
 
 __device__ __forceinline__ bf16x8 frag(const char* lds_tile, int row, int chunk)
 {
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + ((chunk ^ swz((row >> 2) & 3)) << 4));
 }
 
-template <int K, int DBG>
-__global__ __launch_bounds__(512) void k_gemm_bf16_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bt,
-                                                     const float* __restrict__ bias, float* __restrict__ C, int M, int N)
+// ---------------------------------------------------------------------------------------------------------------
+// The GEMM kernel is persistent: one workgroup per CU walks a list of tiles and NEVER drains its pipeline.
+//  * the tile SHAPE is a template parameter, chosen by the launcher so that the tile count fits the CU count: the patch
+//    embedding of a 120-frame clip is 23 520 x 768 outputs -- 276 tiles of 256 x 256 are TWO rounds on 256 CUs with the
+//    second one 8 % full, 248 tiles of 384 x 192 (8 waves as 4 x 2, a wave owns 96 x 96 = 6 x 6 MFMA tiles) are one;
+//  * the half-stage stream is continuous across tiles: during the last steps of a tile the LDS-DMAs of the next tile's
+//    first half stages are already issued -- no prologue latency, no drained ring behind the epilogue;
+//  * the product is formed TRANSPOSED (mfma(b, a): the accumulator tile has n on its rows and m on the lane), so a lane
+//    holds four consecutive COLUMNS of one output row: the epilogue is plain 16-byte (f32) / 8-byte (bf16) stores
+//    straight from the accumulators, no LDS staging, and the ring stays free for the next tile;
+//  * loads and stores of a wave share one in-order vmcnt: the waits of the three steps after an epilogue allow the
+//    stores to be outstanding (vmcnt(2 P + stores)) -- the half stages they wait for were issued BEFORE the stores; from
+//    the fourth step on the stores are older than what is waited for and have long completed;
+//  * the bias sits in LDS (3 KiB) so that the epilogue issues no loads.
+// Tile order: logical workgroup id = (blockIdx % 8) * (grid / 8) + blockIdx / 8 and tile = id + i * grid: the column
+// tiles of one row block of A run at the same time on one XCD.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WAVES_M, int TI, int TJ>
+struct TileShape {
+    static constexpr int WAVES_N = 8 / WAVES_M, TI_ = TI, TJ_ = TJ;
+    static constexpr int BM = WAVES_M * TI * 16, BN = WAVES_N * TJ * 16;
+    static constexpr int RA = BM / 8, RB = BN / 8;              // rows of each operand that one wave stages per half stage
+    static_assert(RA % 8 == 0 && RB % 8 == 0 && TI % 2 == 0, "a wave stages whole or half LDS-DMA instructions (16 / 8 rows)");
+    static constexpr int QA = (RA + 15) / 16, QB = (RB + 15) / 16;   // LDS-DMA instructions (the last one may be half masked)
+    static constexpr int P = QA + QB;                           // ... per wave and half stage
+    static constexpr int HALF_A = BM * BKH * 2, HALF_B = BN * BKH * 2, STAGE = HALF_A + HALF_B;
+    static constexpr int LDS = kStages * STAGE;
+    static_assert(TJ % 2 == 0 && 2 * P + TI * TJ <= 63, "column tiles pair up in the epilogue; vmcnt is six bits");
+};
+
+// R rows per wave of one operand half tile: instruction q covers rows wave * R + q * 16 + lane / 4; when R is an odd
+// multiple of 8 the last instruction is issued for the lower 32 lanes only (8 rows).
+template <int R>
+__device__ __forceinline__ void stage_rows(const char* tile, const unsigned (&voff)[(R + 15) / 16], char* lds_half, int wave, int lane)
 {
-    constexpr int dbg = DBG;                               // timing experiments (AVD_GEMM_DBG), 0 in production
-    extern __shared__ __align__(16) char lds[];            // ring of 4 half stages [A | B]; reused by the epilogue
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, total = tiles_m * tiles_n;
-    // consecutive logical tiles (the N tiles of one M block) on one XCD
-    const int per = (gridDim.x + 7) >> 3;
-    const int lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (lid >= total) return;
-    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
-    constexpr int NH = K / BKH;                            // half stages of this tile (the loop below is fully unrolled)
-
-    f32x4 acc[8][4];
+    constexpr int Q = (R + 15) / 16;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto issue = [&](int hs) __attribute__((always_inline)) {
-        char* st = lds + (hs % kStages) * kStage;
-        if (dbg & 1) return;                               // timing experiment: no global -> LDS traffic
-        stage_half(A, m0, M, K, hs * BKH, st, wave, lane);
-        stage_half(Bt, n0, N, K, hs * BKH, st + kHalfTile, wave, lane);
-    };
-    // Software pipeline over half stages: while the MFMAs of half stage hs run from REGISTERS, the fragments of hs + 1
-    // are read from LDS (the compiler interleaves the two: they are independent) and hs + 2 .. hs + 4 are in flight as
-    // LDS-DMAs.  A half stage's LDS slot is free as soon as every wave holds its fragments, i.e. at the next barrier.
-    // A wave issues 4 LDS-DMA instructions per half stage: vmcnt(4 * y) = "all but the y youngest half stages landed".
-    auto wait_landed = [&](int hs, int issued_last) __attribute__((always_inline)) {      // hs must be readable afterwards
-        __builtin_amdgcn_sched_barrier(0);
-        const int younger = issued_last - hs;                // half stages issued after hs (a wave: 4 instructions each)
-        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);                   // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
-    };
-    auto load_frags = [&](bf16x8 (&a)[8], bf16x8 (&b)[4], int hs) __attribute__((always_inline)) {
-        const char* cur = lds + (hs % kStages) * kStage;
-        const int chunk = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < 8; i++) a[i] = frag(cur, wm * 128 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = frag(cur + kHalfTile, wn * 64 + j * 16 + (lane & 15), chunk);
-    };
-    auto mfma_all = [&](const bf16x8 (&a)[8], const bf16x8 (&b)[4]) __attribute__((always_inline)) {
-        if (dbg & 2) {                                      // timing experiment: no MFMA (keep the fragments alive)
-#pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("" ::"v"(a[i]));
-#pragma unroll
-            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(b[j]));
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    };
-    bf16x8 a0[8], b0[4], a1[8], b1[4];
-#pragma unroll
-    for (int i = 0; i < kStages - 1; i++)
-        if (i < NH) issue(i);
-    wait_landed(0, NH - 1 < kStages - 2 ? NH - 1 : kStages - 2);
-    if (kStages - 1 < NH) issue(kStages - 1);
-    load_frags(a0, b0, 0);
-    // one step: fragments of hs are in (ac, bc); fetch hs + 1 into (an, bn) while multiplying
-    auto step = [&](const bf16x8 (&ac)[8], const bf16x8 (&bc)[4], bf16x8 (&an)[8], bf16x8 (&bn)[4], int hs) __attribute__((always_inline)) {
-        if (hs + 1 < NH) {
-            // stage hs + 1 readable; the barrier also says every wave has the fragments of hs in registers, so the
-            // slot of hs is refilled with hs + kStages
-            wait_landed(hs + 1, hs + kStages - 1 < NH - 1 ? hs + kStages - 1 : NH - 1);
-            if (hs + kStages < NH) issue(hs + kStages);
-            load_frags(an, bn, hs + 1);
-        }
-        mfma_all(ac, bc);
-    };
-#pragma unroll
-    for (int hs = 0; hs < NH; hs += 2) {
-        step(a0, b0, a1, b1, hs);
-        if (hs + 1 < NH) step(a1, b1, a0, b0, hs + 1);
-    }
-    // ---- epilogue: through LDS, so that a store instruction writes four whole 256-byte rows of the wave's 128 x 64
-    // block (the accumulator layout -- column = lane & 15, rows (lane >> 4) * 4 + r -- would give 64-byte pieces and four
-    // times as many store instructions)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // every wave is done with the ring
-    constexpr int PITCH = 68;                              // floats per staged row (64 + pad: 16-byte aligned, 2-way banks)
-    float* reg = reinterpret_cast<float*>(lds) + wave * (32 * PITCH);
-    const int ccol = n0 + wn * 64 + (lane & 15) * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ccol);
-#pragma unroll
-    for (int pass = 0; pass < 4; pass++) {                 // 32 rows of the wave's block per pass (2 MFMA row tiles)
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    reg[(ii * 16 + (lane >> 4) * 4 + r) * PITCH + j * 16 + (lane & 15)] = acc[pass * 2 + ii][j][r];
-        // a wave reads back only what it wrote itself: its own LDS operations are ordered
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int rl = q * 4 + (lane >> 4);
-            const int row = m0 + wm * 128 + pass * 32 + rl;
-            f32x4 v = *reinterpret_cast<const f32x4*>(reg + rl * PITCH + (lane & 15) * 4);
-            v += bv;
-            if (row < M && !(dbg & 4)) *reinterpret_cast<f32x4*>(C + (int64_t)row * N + ccol) = v;
+    for (int q = 0; q < Q; q++) {
+        char* dst = lds_half + (wave * R + q * 16) * 64;
+        if (q * 16 + 16 <= R) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + voff[q]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else if (lane < 32) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + voff[q]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent form of the same GEMM: one workgroup per CU walks a list of tiles and NEVER drains its pipeline.
-//  * the half-stage stream is continuous across tiles: during the last four steps of a tile the LDS-DMAs of the next
-//    tile's first half stages are already issued -- no prologue latency, no drained ring behind the epilogue;
-//  * the product is formed TRANSPOSED (mfma(b, a): the accumulator tile has n on its rows and m on the lane), so a lane
-//    holds four consecutive COLUMNS of one output row: the epilogue is 32 plain 16-byte (f32) / 8-byte (bf16) stores
-//    per wave straight from the accumulators, no LDS staging, and the ring stays free for the next tile;
-//  * loads and stores of a wave share one in-order vmcnt: the waits of the three steps after an epilogue allow the 32
-//    stores to be outstanding (vmcnt(8 + 32)) -- the half stages they wait for were issued BEFORE the stores; from the
-//    fourth step on the stores are older than what is waited for and have long completed;
-//  * the bias sits in LDS (3 KiB) so that the epilogue issues no loads.
-// Tile order: logical workgroup id = (blockIdx % 8) * (grid / 8) + blockIdx / 8 and tile = id + i * grid: the three
-// 256-column tiles of a 256-row block of A run at the same time on one XCD.
-// ---------------------------------------------------------------------------------------------------------------
-template <int K, int OUT_BF16>
-__global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bt,
-                                                                const float* __restrict__ bias, void* __restrict__ Cv, int M, int N)
+// per-lane byte offset, relative to the tile's first block of a half stage, of the 16 bytes a lane copies with
+// instruction q: tile row r = wave * R + q * 16 + lane / 4 lives in block r / 16 (blocks of one half stage are K / 32 KiB
+// apart), at r % 16 * 64 + (lane % 4) * 16 inside it -- the swizzle is already in the data
+template <int R>
+__device__ __forceinline__ void stage_offsets(unsigned (&voff)[(R + 15) / 16], int K, int wave, int lane)
 {
+#pragma unroll
+    for (int q = 0; q < (R + 15) / 16; q++) {
+        const int r = wave * R + q * 16 + (lane >> 2);
+        voff[q] = (unsigned)((r >> 4) * (K >> 5) * 1024 + (r & 15) * 64 + (lane & 3) * 16);
+    }
+}
+
+#define AVD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int K, int OUT_BF16, class T, int DBG = 0>
+__global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bt,
+                                                                const float* __restrict__ bias, void* __restrict__ Cv, int M, int N_)
+{
+    constexpr int N = K;                                   // square weight (the patch embedding): offsets fold into immediates
     extern __shared__ __align__(16) char lds[];            // ring of kStages half stages [A | B], then the bias (N floats)
-    constexpr int NH = K / BKH;
-    static_assert(NH >= kStages + 1 && kStages == 4, "the vmcnt immediates below assume a ring of four");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, total = tiles_m * tiles_n;
+    constexpr int NH = K / BKH, TI = T::TI_, TJ = T::TJ_;
+    static_assert(NH >= kStages + 1 && NH % kStages == 0 && kStages == 4, "the waits below assume a ring of four");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in scalar registers: everything derived from it is uniform
+    const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
+    const int tiles_n = N / T::BN, tiles_m = (M + T::BM - 1) / T::BM, total = tiles_m * tiles_n;
     const int lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (lw >= total) return;
-    float* lbias = reinterpret_cast<float*>(lds + kGemmLds);
+    float* lbias = reinterpret_cast<float*>(lds + T::LDS);
     for (int i = threadIdx.x; i < N; i += 512) lbias[i] = bias ? bias[i] : 0.f;
 
-    f32x4 acc[8][4];
+    f32x4 acc[TI][TJ];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < TI; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // LDS-DMA addressing: a uniform tile pointer (scalar registers) + a per-lane 32-bit byte offset that is the same
-    // for every tile, half stage and operand: row (2 * wave + i) * 16 + lane / 4 of the tile, swizzled chunk.  A is padded
-    // to whole tiles by the caller, so no row needs clamping.
-    unsigned voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int r = (wave * 2 + i) * 16 + (lane >> 2);
-        voff[i] = (unsigned)(r * K + (((lane & 3) ^ swz((r >> 2) & 3)) << 3)) * 2u;
-    }
+    // LDS-DMA addressing: a uniform pointer to the tile's first block of the half stage (scalar registers) + a per-lane
+    // 32-bit byte offset that is the same for every tile and half stage.  A is padded to whole tiles by the caller, so no
+    // row needs clamping.
+    unsigned voa[T::QA], vob[T::QB];
+    stage_offsets<T::RA>(voa, K, wave, lane);
+    stage_offsets<T::RB>(vob, K, wave, lane);
     auto issue = [&](int m0, int n0, int hs, int slot) __attribute__((always_inline)) {
-        char* st = lds + slot * kStage;
-        const char* pa = reinterpret_cast<const char*>(A + (int64_t)m0 * K + hs * BKH);
-        const char* pb = reinterpret_cast<const char*>(Bt + (int64_t)n0 * K + hs * BKH);
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + voff[i]),
-                                             (__attribute__((address_space(3))) void*)(st + (wave * 2 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + voff[i]),
-                                             (__attribute__((address_space(3))) void*)(st + kHalfTile + (wave * 2 + i) * 1024), 16, 0, 0);
-        }
+        if (DBG & 1) return;                                 // timing experiment: no global -> LDS traffic
+        char* st = lds + slot * T::STAGE;
+        stage_rows<T::RA>(reinterpret_cast<const char*>(A + ((int64_t)(m0 >> 4) * (K >> 5) + hs) * 512), voa, st, wave, lane);
+        stage_rows<T::RB>(reinterpret_cast<const char*>(Bt + ((int64_t)(n0 >> 4) * (K >> 5) + hs) * 512), vob, st + T::HALF_A, wave, lane);
     };
     // the product is formed transposed: rows of a 16x16 result = n (B fragment as the first operand), lane column = m
+    // Which weight row feeds which MFMA row is free to choose: MFMA row rho of column tile j takes the wave's local
+    // column (j / 2) * 32 + (rho / 4) * 8 + (j % 2) * 4 + rho % 4, so that a lane (accumulator rows (lane / 16) * 4 + r of
+    // tiles 2 jp and 2 jp + 1) owns EIGHT consecutive columns: one 16-byte store of bf16 tokens per lane, 64 contiguous
+    // bytes per output row and instruction (the natural order gives 8-byte stores, 32 contiguous bytes).  The fragment
+    // reads stay conflict-free: the four row groups of a read have swizzle keys (0, 2, 0, 2) + j % 2, and the lane groups
+    // a ds_read_b128 is served in ({0-3, 12-15} of one chunk, {4-11} of the next) still land in four distinct slots.
+    auto b_row = [&](int j, int rho) __attribute__((always_inline)) {
+        return wn * (TJ * 16) + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3);
+    };
+    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    const unsigned coff = (unsigned)((lane & 15) * N + (lane >> 4) * 8) * ESZ;     // this lane inside a 16-row x 32-column piece
     auto store_tile = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;          // four consecutive columns of this lane
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + col);
+        for (int i = 0; i < TI; i++) {
+            const int row0 = m0 + (wm * TI + i) * 16;                             // uniform
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int row = m0 + wm * 128 + i * 16 + (lane & 15);
-                const f32x4 v = acc[i][j] + bv;
-                if (row < M) {
+            for (int jp = 0; jp < TJ / 2; jp++) {
+                const int col0 = n0 + wn * (TJ * 16) + jp * 32;                   // uniform
+                const float* lb = lbias + col0 + (lane >> 4) * 8;                 // eight consecutive columns of this lane
+                const f32x4 lo = acc[i][2 * jp] + *reinterpret_cast<const f32x4*>(lb);
+                const f32x4 hi = acc[i][2 * jp + 1] + *reinterpret_cast<const f32x4*>(lb + 4);
+                char* piece = static_cast<char*>(Cv) + ((int64_t)row0 * N + col0) * ESZ;   // scalar base, 32-bit lane offset
+                if (row0 + (lane & 15) < M && !(DBG & 4)) {
                     if (OUT_BF16) {
-                        uint2 pk;
-                        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(Cv) + (int64_t)row * N + col) = pk;
+                        uint4 pk;
+                        pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+                        pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+                        pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+                        pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+                        *reinterpret_cast<uint4*>(piece + coff) = pk;
                     } else {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(Cv) + (int64_t)row * N + col) = v;
+                        *reinterpret_cast<f32x4*>(piece + coff) = lo;
+                        *reinterpret_cast<f32x4*>(piece + coff + 16) = hi;
                     }
                 }
             }
         }
     };
+    constexpr int STORES = OUT_BF16 ? TI * TJ / 2 : TI * TJ;   // epilogue store instructions per wave
 
-    int tile = lw;
-    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    // prologue of the first tile only: three half stages in flight
+    // Waves w and w + 4 share a SIMD.  If all eight waves read their fragments and then multiply, the matrix pipe idles
+    // while the LDS serves 96 KiB of reads after every barrier, and the LDS idles while everybody multiplies.  So the two
+    // halves of the workgroup run half a step apart: after the barrier of step hs the EARLY waves (0-3) read the fragments
+    // of half stage hs and then multiply them; the LATE waves (4-7) first multiply the fragments they read during step
+    // hs - 1 and then read those of hs.  One fragment set per wave; the ring slot of hs is still released by the barrier
+    // of step hs + 1.  The late waves finish a tile one step later: their epilogue sits inside step 0 of the next tile.
+    auto run = [&](auto late_c) __attribute__((always_inline)) {
+        constexpr bool LATE = decltype(late_c)::value;
+        bf16x8 a[TI], b[TJ];
+        if (DBG & 8) {
 #pragma unroll
-    for (int hs = 0; hs < kStages - 1; hs++) issue(m0, n0, hs, hs);
-    zero_acc();
-    bool first = true;
-    for (;;) {
-        const int nxt = tile + gridDim.x;
-        const bool more = nxt < total;
-        const int m1 = more ? (nxt / tiles_n) * BM : m0, n1 = more ? (nxt % tiles_n) * BN : n0;
-        // Step hs.  A half stage's ring slot is hs mod 4; NH is a multiple of 4, so the next tile's half stage 0 lands in
-        // slot 0 again and the stream of half stages runs on across tiles.
+            for (int i = 0; i < TI; i++) a[i] = bf16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
 #pragma unroll
-        for (int hs = 0; hs < NH; hs++) {
-            // half stage hs must have landed.  Younger operations of this wave: the two half stages behind it (8 LDS-DMAs),
-            // plus the 32 stores of the previous tile's epilogue during the first three steps of a later tile (the half
-            // stages waited for there were issued BEFORE those stores).  At the end of the stream there are fewer.
-            __builtin_amdgcn_sched_barrier(0);
-            if (hs < 3 && !first) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-            else if (hs == NH - 2 && !more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (hs == NH - 1 && !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            // ... for every wave; the same barrier says everyone has finished reading half stage hs - 1, whose slot is
-            // refilled with stream position hs + 3
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);               // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
-        __builtin_amdgcn_sched_barrier(0);                   // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
-            if (hs + kStages - 1 < NH) issue(m0, n0, hs + kStages - 1, (hs + kStages - 1) % kStages);
-            else if (more) issue(m1, n1, hs + kStages - 1 - NH, (hs + kStages - 1) % kStages);
-            // fragments in two halves: the reads of A rows 64..127 are in flight while the first 16 MFMAs run (a single
-            // "read all, wait, multiply" leaves the matrix pipe idle for an LDS round trip per step: both waves of a SIMD
-            // come out of the barrier together)
-            {
-                const char* cur = lds + (hs % kStages) * kStage;
-                const int chunk = lane >> 4, r16 = lane & 15;
-                bf16x8 b[4], alo[4], ahi[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) b[j] = frag(cur + kHalfTile, wn * 64 + j * 16 + r16, chunk);
-#pragma unroll
-                for (int i = 0; i < 4; i++) alo[i] = frag(cur, wm * 128 + i * 16 + r16, chunk);
-#pragma unroll
-                for (int i = 0; i < 4; i++) ahi[i] = frag(cur, wm * 128 + (i + 4) * 16 + r16, chunk);
-                __builtin_amdgcn_sched_barrier(0);          // all twelve reads are issued before the first MFMA
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], alo[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i + 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], ahi[i], acc[i + 4][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TJ; j++) b[j] = bf16x8{(short)wave, 1, 2, 3, 4, 5, 6, 7};
         }
-        store_tile(m0, n0);
-        if (!more) break;
+        auto read_frags = [&](int hs) __attribute__((always_inline)) {
+            if (DBG & 8) return;                             // timing experiment: no LDS fragment reads
+            const char* cur = lds + (hs % kStages) * T::STAGE;
+            const int chunk = lane >> 4, r16 = lane & 15;
+#pragma unroll
+            for (int j = 0; j < TJ; j++) b[j] = frag(cur + T::HALF_A, b_row(j, r16), chunk);
+#pragma unroll
+            for (int i = 0; i < TI; i++) a[i] = frag(cur, (wm * TI + i) * 16 + r16, chunk);
+        };
+        auto multiply = [&]() __attribute__((always_inline)) {
+            if (DBG & 2) {                                   // timing experiment: no MFMA (keep the fragments alive)
+#pragma unroll
+                for (int i = 0; i < TI; i++) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+                for (int j = 0; j < TJ; j++) asm volatile("" ::"v"(b[j]));
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        };
+        int tile = lw;
+        int m0 = (tile / tiles_n) * T::BM, n0 = (tile % tiles_n) * T::BN;
+        int pm0 = m0, pn0 = n0;                              // late waves: the tile whose last fragments are still to be multiplied
+        // prologue of the first tile only: three half stages in flight
+#pragma unroll
+        for (int hs = 0; hs < kStages - 1; hs++) issue(m0, n0, hs, hs);
         zero_acc();
-        tile = nxt; m0 = m1; n0 = n1;
-        first = false;
-    }
+        bool first = true;
+        for (;;) {
+            const int nxt = tile + gridDim.x;
+            const bool more = nxt < total;
+            const int m1 = more ? (nxt / tiles_n) * T::BM : m0, n1 = more ? (nxt % tiles_n) * T::BN : n0;
+            // Step hs.  A half stage's ring slot is hs mod 4; NH is a multiple of 4, so the next tile's half stage 0 lands in
+            // slot 0 again and the stream of half stages runs on across tiles.
+#pragma unroll
+            for (int hs = 0; hs < NH; hs++) {
+                // half stage hs must have landed.  Younger operations of this wave: the two half stages behind it (2 P
+                // LDS-DMAs), plus the stores of the previous tile's epilogue during the three steps that follow it (the
+                // half stages waited for there were issued BEFORE those stores): steps 0-2 for the early waves, 1-3 for
+                // the late ones.  At the end of the stream there are fewer.
+                __builtin_amdgcn_sched_barrier(0);
+                if (!first && hs >= (LATE ? 1 : 0) && hs < (LATE ? 4 : 3)) AVD_WAIT_VM(2 * T::P + STORES);
+                else if (hs == NH - 2 && !more) AVD_WAIT_VM(T::P);
+                else if (hs == NH - 1 && !more) AVD_WAIT_VM(0);
+                else AVD_WAIT_VM(2 * T::P);
+                // ... for every wave; the same barrier says everyone has finished reading half stage hs - 1, whose slot
+                // is refilled with stream position hs + 3
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);           // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
+                if (hs + kStages - 1 < NH) issue(m0, n0, hs + kStages - 1, (hs + kStages - 1) % kStages);
+                else if (more) issue(m1, n1, hs + kStages - 1 - NH, (hs + kStages - 1) % kStages);
+                if (!LATE) {
+                    read_frags(hs);
+                    __builtin_amdgcn_sched_barrier(0);      // all reads are issued before the first MFMA
+                    multiply();
+                } else {
+                    if (hs > 0) {
+                        multiply();                          // the fragments of hs - 1
+                    } else if (!first) {
+                        multiply();                          // the previous tile's last half stage, then its epilogue
+                        store_tile(pm0, pn0);
+                        zero_acc();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // the MFMAs are issued before the reads that overwrite their operands
+                    read_frags(hs);
+                }
+            }
+            if (!LATE) {
+                store_tile(m0, n0);
+                zero_acc();
+            }
+            pm0 = m0; pn0 = n0;
+            if (!more) break;
+            tile = nxt; m0 = m1; n0 = n1;
+            first = false;
+        }
+        if (LATE) {
+            multiply();
+            store_tile(pm0, pn0);
+        }
+    };
+    if (wave >= 4) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 }  // namespace
+
+// row-major [rows][K] bf16 -> the blocked operand layout (host side, once per weight upload); rows % 16 == 0, K % 32 == 0
+void gemm_block_operand(const uint16_t* src, uint16_t* dst, int rows, int K)
+{
+    for (int r = 0; r < rows; r++)
+        for (int k = 0; k < K; k++) dst[blocked_index(r, k, K)] = src[(size_t)r * K + k];
+}
 
 // tokens[M][768] (device, f32) = patchify(frames) x Wt^T + bias.  d_wt: bf16 [768 out][768 k]; d_bias f32[768] or null.
 int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
@@ -384,36 +364,50 @@ int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt,
                         int M, int N, int K)
 {
     if (M <= 0) return 0;
-    if (N % BN || K != kDim || N > 4096) { ctx->err = "gemm_bf16_nt: N must be a multiple of 256 (<= 4096) and K = 768"; return AVD_ERR_ARG; }
-    static const int dbg = [] { const char* e = std::getenv("AVD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();   // timing experiments only
-    static const int variant = [] { const char* e = std::getenv("AVD_GEMM_VARIANT"); return e ? std::atoi(e) : 0; }();   // f32 tokens: 0 = one tile per workgroup (measured faster), 1 = persistent
-    const int total = ((M + BM - 1) / BM) * (N / BN);
+    if (N != kDim || K != kDim) { ctx->err = "gemm_bf16_nt: built for N = K = 768 (the ViT-B/16 patch embedding)"; return AVD_ERR_ARG; }
+    // tile shape: 0 = by cost, 1 = 256 x 256, 3 = 384 x 192
+    static const int variant = [] { const char* e = std::getenv("AVD_GEMM_VARIANT"); return e ? std::atoi(e) : 0; }();
     auto go = [&](auto kern, int grid, size_t lds, auto... args) -> int {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, args...);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
-    if (variant == 1 || out_bf16) {
-        // one workgroup per CU (LDS: ring + bias), grid a multiple of 8 so that the XCD-aware order is a bijection
-        int grid = ctx->num_cus / 8 * 8;
-        if (grid < 8) grid = 8;
-        if (grid > (total + 7) / 8 * 8) grid = (total + 7) / 8 * 8;
-        const size_t lds = kGemmLds + (size_t)N * sizeof(float);
-        if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1>, grid, lds, d_a, d_bt, d_bias, d_c, M, N);
-        return go(k_gemm_bf16_nt_persistent<kDim, 0>, grid, lds, d_a, d_bt, d_bias, d_c, M, N);
-    }
-    const int grid = (total + 7) / 8 * 8;
-    float* c32 = static_cast<float*>(d_c);
-    switch (dbg) {
+    {
+        // persistent kernel, one workgroup per CU (LDS: ring + bias), grid a multiple of 8 so that the XCD-aware order is
+        // a bijection.  Tile shape: the one whose tile count wastes fewer CU rounds (cost = rounds x tile area).
+        using Sq = TileShape<2, 8, 4>;                      // 256 x 256
+        using Wd = TileShape<4, 6, 6>;                      // 384 x 192
+        auto plan = [&](int bm, int bn, int& grid) -> int64_t {
+            if (N % bn) return INT64_MAX;
+            const int tiles = ((M + bm - 1) / bm) * (N / bn);
+            grid = ctx->num_cus / 8 * 8;
+            if (grid < 8) grid = 8;
+            if (grid > (tiles + 7) / 8 * 8) grid = (tiles + 7) / 8 * 8;
+            return (int64_t)((tiles + grid - 1) / grid) * bm * bn;
+        };
+        int grid_sq = 0, grid_wd = 0;
+        const int64_t cost_sq = plan(Sq::BM, Sq::BN, grid_sq), cost_wd = plan(Wd::BM, Wd::BN, grid_wd);
+        // the 384 x 192 body needs more registers than a wave has (it spills): taken only when it saves a whole round of tiles
+        const bool wide = variant == 3 ? true : variant == 1 ? false : cost_wd * 3 < cost_sq * 2;
+        if (wide && cost_wd == INT64_MAX) { ctx->err = "gemm_bf16_nt: N must be a multiple of 192 for the 384 x 192 tile"; return AVD_ERR_ARG; }
+        const size_t lds = (size_t)(wide ? Wd::LDS : Sq::LDS) + (size_t)N * sizeof(float);
+        if (wide) {
+            if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Wd>, grid_wd, lds, d_a, d_bt, d_bias, d_c, M, N);
+            return go(k_gemm_bf16_nt_persistent<kDim, 0, Wd>, grid_wd, lds, d_a, d_bt, d_bias, d_c, M, N);
+        }
 #ifdef AVD_GEMM_DEBUG
-    case 1: return go(k_gemm_bf16_nt<kDim, 1>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
-    case 2: return go(k_gemm_bf16_nt<kDim, 2>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
-    case 4: return go(k_gemm_bf16_nt<kDim, 4>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
-    case 5: return go(k_gemm_bf16_nt<kDim, 5>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
-    case 6: return go(k_gemm_bf16_nt<kDim, 6>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
-    case 7: return go(k_gemm_bf16_nt<kDim, 7>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+        // timing experiments (tools/gemm_dbg.sh): AVD_GEMM_DBG bits 1 = no LDS-DMA, 2 = no MFMA, 4 = no stores, 8 = no fragment reads
+        static const int dbg = [] { const char* e = std::getenv("AVD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();
+        switch (dbg) {
+#define AVD_DBG_CASE(D) case D: return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq, D>, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+            AVD_DBG_CASE(1) AVD_DBG_CASE(2) AVD_DBG_CASE(4) AVD_DBG_CASE(8) AVD_DBG_CASE(3) AVD_DBG_CASE(5) AVD_DBG_CASE(6) AVD_DBG_CASE(7)
+            AVD_DBG_CASE(9) AVD_DBG_CASE(10) AVD_DBG_CASE(11) AVD_DBG_CASE(13) AVD_DBG_CASE(14) AVD_DBG_CASE(15) AVD_DBG_CASE(12)
+#undef AVD_DBG_CASE
+        default: break;
+        }
 #endif
-    default: return go(k_gemm_bf16_nt<kDim, 0>, grid, (size_t)kGemmLds, d_a, d_bt, d_bias, c32, M, N);
+        if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq>, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+        return go(k_gemm_bf16_nt_persistent<kDim, 0, Sq>, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
     }
 }
