@@ -292,21 +292,30 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
 #pragma unroll
             for (int hs = 0; hs < NH; hs++) {
                 // half stage hs must have landed.  Younger operations of this wave: the two half stages behind it (2 P
-                // LDS-DMAs), plus the stores of the previous tile's epilogue during the three steps that follow it (the
-                // half stages waited for there were issued BEFORE those stores): steps 0-2 for the early waves, 1-3 for
-                // the late ones.  At the end of the stream there are fewer.
+                // LDS-DMAs), plus the stores of the previous tile's epilogue while the half stages waited for were issued
+                // BEFORE those stores: steps 0-2 for the early waves (epilogue at the end of step NH - 1), steps 1-2 for
+                // the late ones (epilogue inside step 0, before that step's refill).  At the end of the stream there are fewer.
                 __builtin_amdgcn_sched_barrier(0);
-                if (!first && hs >= (LATE ? 1 : 0) && hs < (LATE ? 4 : 3)) AVD_WAIT_VM(2 * T::P + STORES);
+                if (!first && hs >= (LATE ? 1 : 0) && hs < 3) AVD_WAIT_VM(2 * T::P + STORES);
                 else if (hs == NH - 2 && !more) AVD_WAIT_VM(T::P);
                 else if (hs == NH - 1 && !more) AVD_WAIT_VM(0);
                 else AVD_WAIT_VM(2 * T::P);
                 // ... for every wave; the same barrier says everyone has finished reading half stage hs - 1, whose slot
-                // is refilled with stream position hs + 3
+                // is refilled with stream position hs + 3 (the late waves' reads of hs - 1 are their last instructions
+                // before this point: they must have returned, not merely been issued)
+                if (LATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);           // nothing (LDS reads, MFMAs) may be scheduled across the wait + barrier
-                if (hs + kStages - 1 < NH) issue(m0, n0, hs + kStages - 1, (hs + kStages - 1) % kStages);
-                else if (more) issue(m1, n1, hs + kStages - 1 - NH, (hs + kStages - 1) % kStages);
+                // refill of the slot of half stage hs - 1 with stream position hs + 3.  A wave can sit at an LDS-DMA
+                // instruction for hundreds of cycles when the L1's miss queue is full, and it issues in order: the early
+                // waves issue theirs first thing (their partner on the SIMD is multiplying), the late waves after their
+                // MFMAs (while the early waves multiply)
+                auto refill = [&]() __attribute__((always_inline)) {
+                    if (hs + kStages - 1 < NH) issue(m0, n0, hs + kStages - 1, (hs + kStages - 1) % kStages);
+                    else if (more) issue(m1, n1, hs + kStages - 1 - NH, (hs + kStages - 1) % kStages);
+                };
                 if (!LATE) {
+                    refill();
                     read_frags(hs);
                     __builtin_amdgcn_sched_barrier(0);      // all reads are issued before the first MFMA
                     multiply();
@@ -319,6 +328,7 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
                         zero_acc();
                     }
                     __builtin_amdgcn_sched_barrier(0);      // the MFMAs are issued before the reads that overwrite their operands
+                    refill();
                     read_frags(hs);
                 }
             }
