@@ -26,6 +26,7 @@ EXPORTS = (
     "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
     "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features",
+    "avd_cnn_param_counts", "avd_cnn_set_weights", "avd_cnn_forward", "avd_cnn_conv",
     "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
@@ -114,6 +115,10 @@ def load() -> C.CDLL:
     L.avd_vit_set_weights.argtypes = [vp, vp, vp]
     L.avd_vit_patch_embed.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float)]
+    L.avd_cnn_param_counts.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.avd_cnn_set_weights.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+    L.avd_cnn_forward.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(C.c_float)]
+    L.avd_cnn_conv.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.avd_audio_features.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int]
     L.avd_comm_unique_id.argtypes = [vp]
     L.avd_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -318,6 +323,47 @@ class Context:
         if out is None and bf16:
             tokens = bf16_bits_to_f32(tokens)
         return tokens, (float(ms.value) if timing_reps > 0 else None)
+
+    # -- CNN extension (ResNet-50-style forward on the matrix cores; never part of ai_score) -------------------------
+    @staticmethod
+    def cnn_param_counts():
+        """-> (weights, biases): elements of the flat parameter arrays of avd_cnn_set_weights."""
+        nw, nb = C.c_size_t(0), C.c_size_t(0)
+        if load().avd_cnn_param_counts(C.byref(nw), C.byref(nb)) != 0:
+            raise RuntimeError("avd_cnn_param_counts failed")
+        return int(nw.value), int(nb.value)
+
+    def cnn_set_weights(self, weights: np.ndarray, biases: np.ndarray):
+        """weights: float32 flat (rounded to bf16, nearest even) or uint16 bf16 bits, in the order documented in avd.h."""
+        w = np.ascontiguousarray(weights).reshape(-1)
+        wbits = w if w.dtype == np.uint16 else f32_to_bf16_bits(w.astype(np.float32, copy=False))
+        b = np.ascontiguousarray(biases, np.float32).reshape(-1)
+        self._check(self._L.avd_cnn_set_weights(self._h, wbits.ctypes.data, wbits.size, b.ctypes.data, b.size))
+
+    def cnn_forward(self, frames, timing_reps: int = 0):
+        """-> (logits float32 [N,1000], forward_ms or None)."""
+        ptr, mem, n, h, w, rs, fs, keep = self._frames_ptr(frames)
+        logits = np.empty((n, 1000), np.float32)
+        ms = C.c_float(0.0)
+        self._check(self._L.avd_cnn_forward(self._h, ptr, mem, n, h, w, rs, fs, logits.ctypes.data, int(timing_reps), C.byref(ms)))
+        return logits, (float(ms.value) if timing_reps > 0 else None)
+
+    def cnn_conv(self, x: np.ndarray, w: np.ndarray, bias: np.ndarray, stride: int = 1, relu: bool = True, residual=None) -> np.ndarray:
+        """One convolution layer (test entry).  x float32 NHWC [n,h,w,cin] and w float32 [cout,k,k,cin] are rounded to bf16;
+        -> float32 NHWC (the widened bf16 output)."""
+        n, hin, win, cin = x.shape
+        cout, k, k2, cin2 = w.shape
+        assert k == k2 and cin == cin2
+        pad = k // 2
+        hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        xb = f32_to_bf16_bits(np.ascontiguousarray(x, np.float32))
+        wb = f32_to_bf16_bits(np.ascontiguousarray(w, np.float32))
+        b = np.ascontiguousarray(bias, np.float32)
+        rb = None if residual is None else f32_to_bf16_bits(np.ascontiguousarray(residual, np.float32).reshape(n, hout, wout, cout))
+        y = np.empty((n, hout, wout, cout), np.uint16)
+        self._check(self._L.avd_cnn_conv(self._h, xb.ctypes.data, n, hin, win, cin, wb.ctypes.data, b.ctypes.data, cout, k, stride,
+                                         int(bool(relu)), None if rb is None else rb.ctypes.data, y.ctypes.data))
+        return bf16_bits_to_f32(y)
 
     # -- audio analyzer (reference app/analyzers/audio.py:40-61 for all windows at once) -----------------------
     def audio_features(self, wav, win: int) -> np.ndarray:

@@ -10,20 +10,6 @@ namespace {
 
 constexpr int kFbChunk = 128;      // Farneback pairs per workspace chunk (bounds HBM scratch)
 
-template <typename T>
-int dev_alloc(avd_ctx* ctx, T*& p, size_t count)
-{
-    if (p) { (void)hipFree(p); p = nullptr; }
-    if (count == 0) return 0;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e != hipSuccess) {
-        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
-        p = nullptr;
-        return AVD_ERR_NOMEM;
-    }
-    return 0;
-}
-
 int rows_per_band_for(int w)
 {
     // LDS tile = (rows+2) * pitch bytes, kept under 48 KiB so that >= 3 workgroups fit a CU
@@ -63,6 +49,8 @@ void free_ws(Workspace& ws)
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
+    F(ws.d_cnn_w); F(ws.d_cnn_b); F(ws.d_cnn_col); F(ws.d_cnn_img); F(ws.d_cnn_pool); F(ws.d_cnn_logits);
+    for (int i = 0; i < 4; i++) F(ws.d_cnn_act[i]);
     if (ws.h_rec) (void)hipHostFree(ws.h_rec);
     ws = Workspace{};
 }
@@ -612,6 +600,47 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     return AVD_ERR_ARG;
 }
 
+// ---- CNN extension (avd_cnn.hip; never part of ai_score) ---------------------------------------------------------
+static int impl_cnn_set_weights(avd_ctx* ctx, const uint16_t* w, size_t n_w, const float* b, size_t n_b)
+{
+    if (!ctx || !w || !b) return AVD_ERR_ARG;
+    size_t want_w = 0, want_b = 0;
+    cnn_param_counts(&want_w, &want_b);
+    if (n_w != want_w || n_b != want_b) { ctx->err = "avd_cnn_set_weights: parameter counts differ from avd_cnn_param_counts"; return AVD_ERR_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return cnn_set_weights(ctx, w, b);
+}
+
+static int impl_cnn_forward(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
+                            float* logits, int reps, float* forward_ms)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if ((!bgr || !logits) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    if (n < 0 || n > 256 || h < 2 || w < 2 || row_stride < (int64_t)w * 3) { ctx->err = "bad frame geometry (at most 256 frames per call)"; return AVD_ERR_ARG; }
+    if (n == 0) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Workspace& ws = ctx->ws;
+    if (!ws.d_cnn_w) { ctx->err = "avd_cnn_set_weights has not been called"; return AVD_ERR_ARG; }
+    if (int e = cnn_reserve(ctx, n)) return e;
+    const uint8_t* d_bgr = nullptr;
+    const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
+    if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
+    if (int e = launch_cnn_forward(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
+    if (reps > 0 && forward_ms) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int r = 0; r < reps; r++)
+            if (int e = launch_cnn_forward(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *forward_ms = ms / reps;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(logits, ws.d_cnn_logits, sizeof(float) * (size_t)n * 1000, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+
 // ---- ViT-B/16 patch embedding (extension; never part of ai_score) ---------------------------------------------
 static int impl_vit_set_weights(avd_ctx* ctx, const uint16_t* w_bf16, const float* bias)
 {
@@ -785,6 +814,34 @@ int avd_analyze_frames(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, 
                        int64_t frame_stride, avd_frame_record* records)
 {
     return guarded(ctx, [&] { return impl_analyze_frames(ctx, bgr, mem, n, h, w, row_stride, frame_stride, records); });
+}
+
+int avd_cnn_param_counts(size_t* n_weights, size_t* n_biases)
+{
+    if (!n_weights || !n_biases) return AVD_ERR_ARG;
+    cnn_param_counts(n_weights, n_biases);
+    return AVD_OK;
+}
+
+int avd_cnn_set_weights(avd_ctx* ctx, const uint16_t* weights_bf16, size_t n_weights, const float* biases, size_t n_biases)
+{
+    return guarded(ctx, [&] { return impl_cnn_set_weights(ctx, weights_bf16, n_weights, biases, n_biases); });
+}
+
+int avd_cnn_forward(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
+                    float* logits, int timing_reps, float* forward_ms)
+{
+    return guarded(ctx, [&] { return impl_cnn_forward(ctx, bgr, mem, n, h, w, row_stride, frame_stride, logits, timing_reps, forward_ms); });
+}
+
+int avd_cnn_conv(avd_ctx* ctx, const uint16_t* x, int n, int hin, int win, int cin, const uint16_t* w, const float* bias,
+                 int cout, int ksize, int stride, int relu, const uint16_t* residual, uint16_t* y)
+{
+    return guarded(ctx, [&] {
+        if (!ctx || !x || !w || !bias || !y) return (int)AVD_ERR_ARG;
+        if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return (int)AVD_ERR_DEVICE; }
+        return cnn_conv_host(ctx, x, n, hin, win, cin, w, bias, cout, ksize, stride, relu, residual, y);
+    });
 }
 
 int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* bias)

@@ -1,0 +1,523 @@
+// avd_cnn.hip -- ResNet-50-style CNN forward on the matrix cores (gfx950): SURVEY.md section 8 row A9.
+//
+// BUILD-DEFINED EXTENSION: the reference has no learned model (its per-frame "model" is the
+// closed form of app/analyzers/video.py:54-56).  BASELINE.json's north_star names a "CNN (ResNet-50-style) forward" on
+// MFMA; this file is that stage with caller-supplied (seeded random) weights, gated off from ai_score: nothing in the
+// parity path calls it.  Its oracle is a float32 restatement with the same bf16 roundings (tests/test_cnn.py).
+//
+// Topology: 7x7/2 stem (64) + ReLU, 3x3/2 max pool, bottleneck stages [3, 4, 6, 3] of widths 64/128/256/512 (x4 out,
+// stride on the 3x3), global average pool, 2048 -> 1000 linear: 53 convolutions, 4.1 GMAC per 224 x 224 frame.  Batch
+// norm is taken as folded into the weights and a per-channel bias.
+//
+// DATA LAYOUT IN HBM: an activation is the matrix [pixels = n * H * W][channels], bf16, in the blocked + swizzled operand
+// layout of avd_mfma_device.h (1-KiB blocks of 16 pixels x 32 channels), preceded by one KiB of zeros.  Every
+// convolution is ONE implicit GEMM  out[pixel][cout] = sum_{tap, c} in[pixel shifted by tap][c] * W[cout][tap][c] :
+//  * the weight operand [cout][K = taps * cin] is re-tiled once on upload: an LDS-DMA instruction copies one KiB block;
+//  * the activation operand is GATHERED by the LDS-DMA itself: lane -> (tile row, 16-byte chunk), so a lane's source
+//    address is "the 8 channels I need of the input pixel this output pixel sees through tap (dy, dx)"; taps that fall
+//    outside the image read the zero page.  No im2col matrix is ever written (the 3-channel stem excepted);
+//  * the epilogue adds bias (+ the residual, read in the same layout), applies ReLU, rounds to bf16 and stores 16 bytes
+//    per lane straight into the blocked layout of the NEXT layer's operand.
+// Tile: 256 pixels x (64 | 128 | 256) output channels per 512-thread workgroup, K in half stages of 32, ring of four half
+// stages with counted vmcnt + raw s_barrier (the scheme of avd_vit.hip; K is a run-time value here).
+#include <cstdlib>
+#include <vector>
+#include "avd_internal.h"
+#include "avd_mfma_device.h"
+
+namespace {
+
+using namespace avd_mfma;
+
+constexpr int kSide = 224;
+constexpr int kZeroPage = 512;                  // elements (1 KiB) of zeros in front of every activation
+
+struct ConvGeom {
+    int hin, win, cin, hout, wout, cout, ksize, stride, pad;
+    int m_out;                                  // n * hout * wout
+    int nh;                                     // half stages: ksize * ksize * cin / 32
+    int cpb;                                    // cin / 32
+};
+
+#define AVD_WAIT_VMC(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int WAVES_M, int TI>
+__global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                  const float* __restrict__ bias, const uint16_t* __restrict__ R,
+                                                  uint16_t* __restrict__ Y, ConvGeom g, int relu)
+{
+    constexpr int WAVES_N = 8 / WAVES_M, TJ = 4, BM = 256, BN = WAVES_N * 64;
+    static_assert(WAVES_M * TI * 16 == BM, "a workgroup covers 256 output pixels");
+    constexpr int RB = BN / 8;                              // weight rows a wave stages per half stage: 32, 16 or 8
+    constexpr int QB = (RB + 15) / 16;
+    constexpr int P = 2 + QB;                               // LDS-DMA instructions per wave and half stage
+    constexpr int HALF_A = BM * 64, HALF_B = BN * 64, STAGE = HALF_A + HALF_B;
+    extern __shared__ __align__(16) char lds[];            // ring of four half stages [A | B]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = g.cout / BN, tiles_m = (g.m_out + BM - 1) / BM, total = tiles_m * tiles_n;
+    // the column tiles of one pixel block run together on one XCD (the gathered activation rows are fetched once)
+    const int per = (gridDim.x + 7) >> 3;
+    const int lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lid >= total) return;
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+    // ---- the two activation rows this lane gathers per half stage (instruction q: tile row wave * 32 + q * 16 + lane / 4)
+    int gy[2], gx[2], gb[2], cw[2];
+    bool gv[2];
+    const int hw = g.hout * g.wout;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int r = wave * 32 + q * 16 + (lane >> 2), m = m0 + r;
+        gv[q] = m < g.m_out;
+        const int img = m / hw, rem = m - img * hw, oy = rem / g.wout, ox = rem - oy * g.wout;
+        gy[q] = oy * g.stride - g.pad;
+        gx[q] = ox * g.stride - g.pad;
+        gb[q] = img * g.hin * g.win;
+        cw[q] = (lane & 3) ^ swz((r >> 2) & 3);             // the chunk that belongs in this lane's LDS slot
+    }
+    unsigned vob[QB];
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+        const int r = wave * RB + q * 16 + (lane >> 2);
+        vob[q] = (unsigned)((r >> 4) * g.nh * 1024 + (r & 15) * 64 + (lane & 3) * 16);
+    }
+    const char* xb = reinterpret_cast<const char*>(X);
+    int is_cb = 0, is_dy = 0, is_dx = 0;                    // channel block and tap of the next half stage to be issued
+    auto issue = [&](int hs) __attribute__((always_inline)) {
+        char* st = lds + (hs & 3) * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int yi = gy[q] + is_dy, xi = gx[q] + is_dx;
+            const bool ok = gv[q] && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win;
+            const int rin = gb[q] + yi * g.win + xi;
+            unsigned off = (unsigned)(kZeroPage * 2) + (unsigned)((rin >> 4) * g.cpb + is_cb) * 1024u + (unsigned)((rin & 15) * 64) +
+                           (unsigned)((cw[q] ^ swz((rin >> 2) & 3)) << 4);
+            off = ok ? off : (unsigned)(lane * 16);           // outside the image (or past the last pixel): the zero page
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * 32 + q * 16) * 64), 16, 0, 0);
+        }
+        const char* wb = reinterpret_cast<const char*>(Wt + ((int64_t)(n0 >> 4) * g.nh + hs) * 512);
+#pragma unroll
+        for (int q = 0; q < QB; q++) {
+            char* dst = st + HALF_A + (wave * RB + q * 16) * 64;
+            if (q * 16 + 16 <= RB) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + vob[q]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else if (lane < 32) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + vob[q]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+        if (++is_cb == g.cpb) {
+            is_cb = 0;
+            if (++is_dx == g.ksize) { is_dx = 0; ++is_dy; }
+        }
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight row -> MFMA row permutation of avd_vit.hip: a lane ends up with eight consecutive output channels
+    auto b_row = [&](int j, int rho) __attribute__((always_inline)) {
+        return wn * 64 + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3);
+    };
+
+    const int nh = g.nh;
+    for (int hs = 0; hs < 3 && hs < nh; hs++) issue(hs);
+    for (int hs = 0; hs < nh; hs++) {
+        // half stage hs must have landed; younger LDS-DMAs of this wave: the half stages issued after it
+        __builtin_amdgcn_sched_barrier(0);
+        const int younger = (hs + 2 < nh - 1 ? hs + 2 : nh - 1) - hs;
+        if (younger >= 2) AVD_WAIT_VMC(2 * P);
+        else if (younger == 1) AVD_WAIT_VMC(P);
+        else AVD_WAIT_VMC(0);
+        __builtin_amdgcn_s_barrier();                        // ... for every wave, and everyone is done with half stage hs - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (hs + 3 < nh) issue(hs + 3);
+        const char* cur = lds + (hs & 3) * STAGE;
+        const int chunk = lane >> 4, r16 = lane & 15;
+        bf16x8 a[TI], b[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; j++) b[j] = frag(cur + HALF_A, b_row(j, r16), chunk);
+#pragma unroll
+        for (int i = 0; i < TI; i++) a[i] = frag(cur, (wm * TI + i) * 16 + r16, chunk);
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: bias (+ residual), ReLU, bf16, 16 bytes per lane into the blocked layout of the next operand
+    const unsigned loff = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ swz((lane >> 2) & 3)) << 4));
+    const int cblocks = g.cout >> 5;
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+        const int rblk = (m0 >> 4) + wm * TI + i;
+#pragma unroll
+        for (int jp = 0; jp < TJ / 2; jp++) {
+            const int col0 = n0 + wn * 64 + jp * 32;
+            const float* pb = bias + col0 + (lane >> 4) * 8;
+            f32x4 lo = acc[i][2 * jp] + *reinterpret_cast<const f32x4*>(pb);
+            f32x4 hi = acc[i][2 * jp + 1] + *reinterpret_cast<const f32x4*>(pb + 4);
+            const int64_t boff = (int64_t)kZeroPage * 2 + ((int64_t)rblk * cblocks + (col0 >> 5)) * 1024;
+            if (R) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(R) + boff + loff);
+                lo[0] += bf16_to_f32(rv.x & 0xFFFF); lo[1] += bf16_to_f32(rv.x >> 16);
+                lo[2] += bf16_to_f32(rv.y & 0xFFFF); lo[3] += bf16_to_f32(rv.y >> 16);
+                hi[0] += bf16_to_f32(rv.z & 0xFFFF); hi[1] += bf16_to_f32(rv.z >> 16);
+                hi[2] += bf16_to_f32(rv.w & 0xFFFF); hi[3] += bf16_to_f32(rv.w >> 16);
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+            }
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+            pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + boff + loff) = pk;
+        }
+    }
+}
+
+// BGR uint8 frame -> 224 x 224 (float bilinear taps, cv2's INTER_LINEAR centre mapping), RGB, (x / 255 - mean) / std,
+// bf16: img[frame * 224 * 224 + y * 224 + x][4] (fourth channel zero).  Same arithmetic as k_vit_patchify.
+__global__ __launch_bounds__(256) void k_cnn_input(const uint8_t* __restrict__ bgr, int n, int h, int w, int64_t row_stride,
+                                                  int64_t frame_stride, uint16_t* __restrict__ img)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * kSide * kSide) return;
+    const int x = gid % kSide, y = (gid / kSide) % kSide, f = gid / (kSide * kSide);
+    const float sx = (float)w / kSide, sy = (float)h / kSide;
+    float fx = (x + 0.5f) * sx - 0.5f, fy = (y + 0.5f) * sy - 0.5f;
+    int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    fx -= x0; fy -= y0;
+    if (x0 < 0) { x0 = 0; fx = 0.f; }
+    if (x0 >= w - 1) { x0 = w - 1; fx = 0.f; }
+    if (y0 < 0) { y0 = 0; fy = 0.f; }
+    if (y0 >= h - 1) { y0 = h - 1; fy = 0.f; }
+    const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    const uint8_t* fr = bgr + (int64_t)f * frame_stride;
+    const uint8_t *p00 = fr + (int64_t)y0 * row_stride + x0 * 3, *p01 = fr + (int64_t)y0 * row_stride + x1 * 3;
+    const uint8_t *p10 = fr + (int64_t)y1 * row_stride + x0 * 3, *p11 = fr + (int64_t)y1 * row_stride + x1 * 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};   // RGB (ImageNet)
+    uint16_t v4[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int s = 2 - c;
+        const float top = p00[s] + (p01[s] - (float)p00[s]) * fx, bot = p10[s] + (p11[s] - (float)p10[s]) * fx;
+        const float v = top + (bot - top) * fy;
+        v4[c] = f32_to_bf16((v * (1.f / 255.f) - mean[c]) * istd[c]);
+    }
+    uint2 pk;
+    pk.x = v4[0] | ((unsigned)v4[1] << 16);
+    pk.y = v4[2];
+    reinterpret_cast<uint2*>(img)[gid] = pk;
+}
+
+// im2col of the 7x7/2 (pad 3) stem: row = (frame, oy, ox) of the 112 x 112 output, k = (ky * 7 + kx) * 3 + c for k < 147,
+// zero up to 160; one thread = 8 consecutive k of one row = one 16-byte chunk of the blocked operand
+__global__ __launch_bounds__(256) void k_stem_im2col(const uint16_t* __restrict__ img, int n, uint16_t* __restrict__ A)
+{
+    constexpr int HO = 112, K = 160;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)n * HO * HO * (K / 8)) return;
+    const int c8 = (int)(gid % (K / 8));
+    const int m = (int)(gid / (K / 8));
+    const int f = m / (HO * HO), rem = m - f * HO * HO, oy = rem / HO, ox = rem - oy * HO;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = c8 * 8 + e;
+        unsigned short val = 0;
+        if (k < 147) {
+            const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+            const int yi = oy * 2 - 3 + ky, xi = ox * 2 - 3 + kx;
+            if ((unsigned)yi < (unsigned)kSide && (unsigned)xi < (unsigned)kSide) val = img[((int64_t)(f * kSide + yi) * kSide + xi) * 4 + c];
+        }
+        v[e] = val;
+    }
+    uint4 pk;
+    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
+    pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<uint4*>(A + kZeroPage + blocked_index(m, c8 * 8, K)) = pk;
+}
+
+__device__ __forceinline__ unsigned max_bf16x2(unsigned a, unsigned b)     // inputs are >= 0 (after a ReLU): integer order = value order
+{
+    const unsigned lo = max(a & 0xFFFFu, b & 0xFFFFu), hi = max(a >> 16, b >> 16);
+    return lo | (hi << 16);
+}
+
+// 3x3 / 2 max pool (pad 1) over a blocked [n * hin * win][c] activation of non-negative values
+__global__ __launch_bounds__(256) void k_maxpool3(const uint16_t* __restrict__ X, int n, int hin, int win, int c, uint16_t* __restrict__ Y)
+{
+    const int hout = hin / 2, wout = win / 2, c8n = c / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)n * hout * wout * c8n) return;
+    const int c8 = (int)(gid % c8n);
+    const int m = (int)(gid / c8n);
+    const int f = m / (hout * wout), rem = m - f * hout * wout, oy = rem / wout, ox = rem - oy * wout;
+    uint4 best = {0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int yi = oy * 2 - 1 + dy, xi = ox * 2 - 1 + dx;
+            if ((unsigned)yi < (unsigned)hin && (unsigned)xi < (unsigned)win) {
+                const uint4 v = *reinterpret_cast<const uint4*>(X + kZeroPage + blocked_index((f * hin + yi) * win + xi, c8 * 8, c));
+                best.x = max_bf16x2(best.x, v.x); best.y = max_bf16x2(best.y, v.y);
+                best.z = max_bf16x2(best.z, v.z); best.w = max_bf16x2(best.w, v.w);
+            }
+        }
+    *reinterpret_cast<uint4*>(Y + kZeroPage + blocked_index(m, c8 * 8, c)) = best;
+}
+
+// global average pool: blocked [n * hw][c] -> f32 [n][c] (sum in f32 in pixel order, then / hw)
+__global__ __launch_bounds__(256) void k_avgpool(const uint16_t* __restrict__ X, int n, int hw, int c, float* __restrict__ out)
+{
+    const int c8n = c / 8;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * c8n) return;
+    const int c8 = gid % c8n, f = gid / c8n;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < hw; p++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(X + kZeroPage + blocked_index(f * hw + p, c8 * 8, c));
+        s[0] += bf16_to_f32(v.x & 0xFFFF); s[1] += bf16_to_f32(v.x >> 16); s[2] += bf16_to_f32(v.y & 0xFFFF); s[3] += bf16_to_f32(v.y >> 16);
+        s[4] += bf16_to_f32(v.z & 0xFFFF); s[5] += bf16_to_f32(v.z >> 16); s[6] += bf16_to_f32(v.w & 0xFFFF); s[7] += bf16_to_f32(v.w >> 16);
+    }
+    const float inv = 1.f / hw;
+#pragma unroll
+    for (int e = 0; e < 8; e++) out[(int64_t)f * c + c8 * 8 + e] = s[e] * inv;
+}
+
+// logits[f][o] = pooled[f][:] . W[o][:] + b[o]; one wave per output (lane-strided k, then a butterfly sum)
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const uint16_t* __restrict__ W, const float* __restrict__ b,
+                                               int n, int k, int nout, float* __restrict__ y)
+{
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= n * nout) return;
+    const int f = wid / nout, o = wid - f * nout;
+    float s = 0.f;
+    for (int i = lane; i < k; i += 64) s = __builtin_fmaf(x[(int64_t)f * k + i], bf16_to_f32(W[(int64_t)o * k + i]), s);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) y[wid] = s + b[o];
+}
+
+// ---- network description -----------------------------------------------------------------------------------------
+struct Layer { int cin, cout, ksize, stride; size_t w_off, b_off; };        // offsets into the flat parameter arrays (elements)
+
+struct Net {
+    std::vector<Layer> convs;          // stem, then per block: conv1, conv2, conv3 [, downsample]
+    size_t n_w = 0, n_b = 0;           // including the final linear layer
+    size_t fc_w = 0, fc_b = 0;
+    Net()
+    {
+        auto add = [&](int cin, int cout, int k, int s) {
+            convs.push_back({cin, cout, k, s, n_w, n_b});
+            n_w += (size_t)cout * k * k * cin;
+            n_b += cout;
+        };
+        add(3, 64, 7, 2);
+        const int depth[4] = {3, 4, 6, 3};
+        int cin = 64;
+        for (int st = 0; st < 4; st++) {
+            const int mid = 64 << st, out = mid * 4;
+            for (int b = 0; b < depth[st]; b++) {
+                const int s = (b == 0 && st > 0) ? 2 : 1;
+                add(cin, mid, 1, 1);
+                add(mid, mid, 3, s);
+                add(mid, out, 1, 1);
+                if (b == 0) add(cin, out, 1, s);
+                cin = out;
+            }
+        }
+        fc_w = n_w; fc_b = n_b;
+        n_w += (size_t)1000 * 2048;
+        n_b += 1000;
+    }
+};
+const Net& net() { static const Net n; return n; }
+
+int k_padded(const Layer& l) { return l.ksize == 7 ? 160 : l.ksize * l.ksize * l.cin; }   // the stem's 147 taps are padded to 160
+
+int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res, uint16_t* y, int n, int hin,
+                int win, int cin, int cout, int ksize, int stride, int relu)
+{
+    ConvGeom g;
+    g.hin = hin; g.win = win; g.cin = cin; g.cout = cout; g.ksize = ksize; g.stride = stride; g.pad = ksize / 2;
+    g.hout = (hin + 2 * g.pad - ksize) / stride + 1;
+    g.wout = (win + 2 * g.pad - ksize) / stride + 1;
+    g.m_out = n * g.hout * g.wout;
+    g.cpb = cin / 32;
+    g.nh = ksize * ksize * g.cpb;
+    if (cin % 32 || cout % 64 || (ksize != 1 && ksize != 3)) { ctx->err = "conv: cin % 32, cout % 64, ksize 1 or 3"; return AVD_ERR_ARG; }
+    const int tiles_m = (g.m_out + 255) / 256;
+    auto go = [&](auto kern, int bn) -> int {
+        const int total = tiles_m * (cout / bn), grid = (total + 7) / 8 * 8;
+        const size_t lds = 4 * (size_t)(256 * 64 + bn * 64);
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, x, w, bias, res, y, g, relu);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
+    if (cout % 256 == 0) return go(k_conv_bf16<2, 8>, 256);
+    if (cout % 128 == 0) return go(k_conv_bf16<4, 4>, 128);
+    return go(k_conv_bf16<8, 2>, 64);
+}
+
+size_t act_elems(size_t rows, int c) { return kZeroPage + (rows + 255) / 256 * 256 * (size_t)c; }
+
+}  // namespace
+
+void cnn_param_counts(size_t* n_w, size_t* n_b) { *n_w = net().n_w; *n_b = net().n_b; }
+
+// flat parameters (conv weights [cout][kh][kw][cin] bf16 in network order, then the linear layer [1000][2048]; biases
+// f32 in the same order) -> device: every convolution's weight re-tiled into the blocked operand layout
+int cnn_set_weights(avd_ctx* ctx, const uint16_t* w, const float* b)
+{
+    const Net& nt = net();
+    Workspace& ws = ctx->ws;
+    size_t blocked_total = 0;
+    for (const Layer& l : nt.convs) blocked_total += (size_t)l.cout * k_padded(l);
+    std::vector<uint16_t> host(blocked_total + (size_t)1000 * 2048), tmp;
+    size_t off = 0;
+    ws.cnn_w_off.clear();
+    for (const Layer& l : nt.convs) {
+        const int K = k_padded(l), kin = l.ksize * l.ksize * l.cin;
+        const uint16_t* src = w + l.w_off;
+        if (K != kin) {                                      // the stem: pad every output channel's 147 taps to 160
+            tmp.assign((size_t)l.cout * K, 0);
+            for (int o = 0; o < l.cout; o++)
+                for (int k = 0; k < kin; k++) tmp[(size_t)o * K + k] = src[(size_t)o * kin + k];
+            src = tmp.data();
+        }
+        gemm_block_operand(src, host.data() + off, l.cout, K);
+        ws.cnn_w_off.push_back(off);
+        off += (size_t)l.cout * K;
+    }
+    ws.cnn_fc_off = off;
+    for (size_t i = 0; i < (size_t)1000 * 2048; i++) host[off + i] = w[nt.fc_w + i];
+    if (!ws.d_cnn_w) if (int e = dev_alloc(ctx, ws.d_cnn_w, host.size())) return e;
+    if (!ws.d_cnn_b) if (int e = dev_alloc(ctx, ws.d_cnn_b, nt.n_b)) return e;
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_cnn_w, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_cnn_b, b, nt.n_b * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+
+// activation scratch for n frames: the stem's im2col operand, four rotating activations, the 224 x 224 input, pooled features
+int cnn_reserve(avd_ctx* ctx, int n)
+{
+    Workspace& ws = ctx->ws;
+    if (n <= ws.cnn_frames) return AVD_OK;
+    const size_t act = act_elems((size_t)n * 112 * 112, 64);             // the largest activation (= n * 56 * 56 x 256)
+    for (int i = 0; i < 4; i++) {
+        if (int e = dev_alloc(ctx, ws.d_cnn_act[i], act)) return e;
+        HIP_TRY(ctx, hipMemsetAsync(ws.d_cnn_act[i], 0, kZeroPage * sizeof(uint16_t), ctx->stream));
+    }
+    if (int e = dev_alloc(ctx, ws.d_cnn_col, act_elems((size_t)n * 112 * 112, 160))) return e;
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_cnn_col, 0, kZeroPage * sizeof(uint16_t), ctx->stream));
+    if (int e = dev_alloc(ctx, ws.d_cnn_img, (size_t)n * kSide * kSide * 4)) return e;
+    if (int e = dev_alloc(ctx, ws.d_cnn_pool, (size_t)n * 2048)) return e;
+    if (int e = dev_alloc(ctx, ws.d_cnn_logits, (size_t)n * 1000)) return e;
+    ws.cnn_frames = n;
+    return AVD_OK;
+}
+
+// frames (device BGR) -> logits (device f32 [n][1000]); everything on ctx->stream
+int launch_cnn_forward(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride)
+{
+    const Net& nt = net();
+    Workspace& ws = ctx->ws;
+    const int64_t px = (int64_t)n * kSide * kSide;
+    hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, n, h, w, row_stride, frame_stride, ws.d_cnn_img);
+    const int64_t chunks = (int64_t)n * 112 * 112 * 20;
+    hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_img, n, ws.d_cnn_col);
+    size_t li = 0;
+    auto wptr = [&](size_t i) { return ws.d_cnn_w + ws.cnn_w_off[i]; };
+    auto bptr = [&](size_t i) { return ws.d_cnn_b + nt.convs[i].b_off; };
+    // the stem as a 1x1 convolution over its im2col operand (K = 160)
+    if (int e = launch_conv(ctx, ws.d_cnn_col, wptr(0), bptr(0), nullptr, ws.d_cnn_act[0], n, 112, 112, 160, 64, 1, 1, 1)) return e;
+    li = 1;
+    const int64_t pooled = (int64_t)n * 56 * 56 * 8;
+    hipLaunchKernelGGL(k_maxpool3, dim3((unsigned)((pooled + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_act[0], n, 112, 112, 64, ws.d_cnn_act[1]);
+    int cur = 1, hgt = 56;                                   // index of the block input among the four rotating buffers
+    const int depth[4] = {3, 4, 6, 3};
+    int cin = 64;
+    for (int st = 0; st < 4; st++) {
+        const int mid = 64 << st, out = mid * 4;
+        for (int b = 0; b < depth[st]; b++) {
+            const int s = (b == 0 && st > 0) ? 2 : 1;
+            const int t1 = (cur + 1) & 3, t2 = (cur + 2) & 3, sc = (cur + 3) & 3;
+            uint16_t *x = ws.d_cnn_act[cur], *a1 = ws.d_cnn_act[t1], *a2 = ws.d_cnn_act[t2], *a3 = ws.d_cnn_act[sc];
+            if (int e = launch_conv(ctx, x, wptr(li), bptr(li), nullptr, a1, n, hgt, hgt, cin, mid, 1, 1, 1)) return e;
+            if (int e = launch_conv(ctx, a1, wptr(li + 1), bptr(li + 1), nullptr, a2, n, hgt, hgt, mid, mid, 3, s, 1)) return e;
+            const int ho = hgt / s;
+            const uint16_t* res = x;
+            if (b == 0) {                                    // projection shortcut into a3, then conv3 writes over a1
+                if (int e = launch_conv(ctx, x, wptr(li + 3), bptr(li + 3), nullptr, a3, n, hgt, hgt, cin, out, 1, s, 0)) return e;
+                res = a3;
+            }
+            if (int e = launch_conv(ctx, a2, wptr(li + 2), bptr(li + 2), res, a1, n, ho, ho, mid, out, 1, 1, 1)) return e;
+            li += b == 0 ? 4 : 3;
+            cur = t1; hgt = ho; cin = out;
+        }
+    }
+    hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n * 256 + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_act[cur], n, 49, 2048, ws.d_cnn_pool);
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)((n * 1000 + 3) / 4)), dim3(256), 0, ctx->stream, ws.d_cnn_pool, ws.d_cnn_w + ws.cnn_fc_off,
+                       ws.d_cnn_b + nt.fc_b, n, 2048, 1000, ws.d_cnn_logits);
+    HIP_TRY(ctx, hipGetLastError());
+    return AVD_OK;
+}
+
+// ONE convolution on host tensors in NHWC order (test entry: the blocked layout stays an internal matter)
+int cnn_conv_host(avd_ctx* ctx, const uint16_t* x, int n, int hin, int win, int cin, const uint16_t* w, const float* bias, int cout, int ksize,
+                  int stride, int relu, const uint16_t* residual, uint16_t* y)
+{
+    if (cin % 32 || cout % 64 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || n <= 0) {
+        ctx->err = "cnn_conv: cin % 32 == 0, cout % 64 == 0, ksize 1 or 3, stride 1 or 2";
+        return AVD_ERR_ARG;
+    }
+    const int pad = ksize / 2, hout = (hin + 2 * pad - ksize) / stride + 1, wout = (win + 2 * pad - ksize) / stride + 1;
+    const size_t min_ = (size_t)n * hin * win, mout = (size_t)n * hout * wout;
+    const int K = ksize * ksize * cin;
+    std::vector<uint16_t> hx(act_elems(min_, cin), 0), hw((size_t)cout * K), hr, hy(act_elems(mout, cout), 0);
+    for (size_t m = 0; m < min_; m++)
+        for (int c = 0; c < cin; c++) hx[kZeroPage + blocked_index((int)m, c, cin)] = x[m * cin + c];
+    gemm_block_operand(w, hw.data(), cout, K);
+    if (residual) {
+        hr.assign(act_elems(mout, cout), 0);
+        for (size_t m = 0; m < mout; m++)
+            for (int c = 0; c < cout; c++) hr[kZeroPage + blocked_index((int)m, c, cout)] = residual[m * cout + c];
+    }
+    uint16_t *dx = nullptr, *dw = nullptr, *dr = nullptr, *dy = nullptr;
+    float* db = nullptr;
+    int rc = AVD_OK;
+    auto cleanup = [&]() { (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dr); (void)hipFree(dy); (void)hipFree(db); };
+#define CNN_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->err = hipGetErrorString(e_); cleanup(); return AVD_ERR_DEVICE; } } while (0)
+    CNN_TRY(hipMalloc(&dx, hx.size() * 2)); CNN_TRY(hipMalloc(&dw, hw.size() * 2)); CNN_TRY(hipMalloc(&dy, hy.size() * 2));
+    CNN_TRY(hipMalloc(&db, cout * sizeof(float)));
+    if (residual) CNN_TRY(hipMalloc(&dr, hr.size() * 2));
+    CNN_TRY(hipMemcpyAsync(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    CNN_TRY(hipMemcpyAsync(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    CNN_TRY(hipMemcpyAsync(db, bias, cout * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CNN_TRY(hipMemsetAsync(dy, 0, hy.size() * 2, ctx->stream));
+    if (residual) CNN_TRY(hipMemcpyAsync(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_conv(ctx, dx, dw, db, dr, dy, n, hin, win, cin, cout, ksize, stride, relu);
+    if (rc == AVD_OK) {
+        CNN_TRY(hipMemcpyAsync(hy.data(), dy, hy.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+        CNN_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t m = 0; m < mout; m++)
+            for (int c = 0; c < cout; c++) y[m * cout + c] = hy[kZeroPage + blocked_index((int)m, c, cout)];
+    }
+#undef CNN_TRY
+    cleanup();
+    return rc;
+}

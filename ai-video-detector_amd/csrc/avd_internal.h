@@ -119,6 +119,11 @@ struct Workspace {
     double* d_audio_tab = nullptr; size_t audio_tab_elems = 0; int audio_win = 0, audio_last = 0;
     double* d_audio_buf = nullptr; size_t audio_buf_elems = 0;
     avd_audio_window* d_audio_out = nullptr; size_t audio_out_elems = 0;
+    // CNN extension (avd_cnn.hip): blocked conv weights + linear layer, biases, activation scratch for cnn_frames frames
+    uint16_t* d_cnn_w = nullptr; float* d_cnn_b = nullptr;
+    std::vector<size_t> cnn_w_off; size_t cnn_fc_off = 0;
+    uint16_t* d_cnn_act[4] = {}; uint16_t* d_cnn_col = nullptr; uint16_t* d_cnn_img = nullptr;
+    float* d_cnn_pool = nullptr; float* d_cnn_logits = nullptr; int cnn_frames = 0;
 };
 
 struct avd_ctx {
@@ -146,6 +151,20 @@ struct avd_ctx {
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
 };
 
+template <typename T>
+inline int dev_alloc(avd_ctx* ctx, T*& p, size_t count)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        p = nullptr;
+        return AVD_ERR_NOMEM;
+    }
+    return 0;
+}
+
 // ---- stage launchers (each enqueues on ctx->stream) --------------------------------
 int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w);
 int avd_ws_reserve_fb(avd_ctx* ctx, int n);
@@ -164,6 +183,13 @@ void gemm_block_operand(const uint16_t* src_row_major, uint16_t* dst_blocked, in
 constexpr int kGemmRowPad = 768;     // lcm of the GEMM's tile heights (256, 384): A is allocated in multiples of it
 int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, void* d_c, int out_bf16,
                         int M, int N, int K);
+// avd_cnn.hip (extension): ResNet-50-style forward as implicit GEMMs on the matrix cores
+void cnn_param_counts(size_t* n_weights, size_t* n_biases);
+int cnn_set_weights(avd_ctx* ctx, const uint16_t* weights, const float* biases);
+int cnn_reserve(avd_ctx* ctx, int n);
+int launch_cnn_forward(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride);
+int cnn_conv_host(avd_ctx* ctx, const uint16_t* x, int n, int hin, int win, int cin, const uint16_t* w, const float* bias, int cout, int ksize,
+                  int stride, int relu, const uint16_t* residual, uint16_t* y);
 // avd_comm.cpp: RCCL all-gather of the per-frame records (dlopen, no link-time dependency)
 int comm_unique_id(std::string& err, void* id128);
 int comm_init(avd_ctx* ctx, int rank, int world, const void* id128);

@@ -27,34 +27,14 @@
 #include <cstdlib>
 #include <type_traits>
 #include "avd_internal.h"
+#include "avd_mfma_device.h"
 
 namespace {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace avd_mfma;
 
 constexpr int kPatch = 16, kSide = 224, kGrid = kSide / kPatch, kTokens = kGrid * kGrid;   // 14 x 14 = 196 patches
 constexpr int kDim = 3 * kPatch * kPatch;                                                  // 768
-
-__device__ __forceinline__ uint16_t f32_to_bf16(float v)
-{
-    const unsigned u = __float_as_uint(v);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);       // round to nearest even (inputs are finite)
-}
-
-// Bank swizzle of a half tile (64-byte rows, four 16-byte chunks per row, four rows per 256-byte bank row): chunk c of
-// row r sits in slot c ^ swz((r >> 2) & 3).  A ds_read_b128 is served in groups of 16 lanes that are NOT contiguous
-// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...): with lane = (chunk << 4) | row a group reads rows {0-3, 12-15} of
-// one chunk and rows {4-11} of the next, and swz = {0, 2, 3, 1} is what makes those sixteen accesses hit sixteen
-// different 16-byte bank groups (the plain XOR with (r >> 2) & 3 is two-way conflicted for these groups).
-__host__ __device__ __forceinline__ int swz(int k) { return k ? (k % 3) + 1 : 0; }
-
-// element index of (row, k) in the blocked operand layout (see the head of this file)
-__host__ __device__ __forceinline__ int64_t blocked_index(int row, int k, int K)
-{
-    const int r = row & 15, kk = k & 31;
-    return ((int64_t)(row >> 4) * (K >> 5) + (k >> 5)) * 512 + r * 32 + (((kk >> 3) ^ swz((r >> 2) & 3)) << 3) + (kk & 7);
-}
 
 // one thread = one output pixel (x, y) of one frame, three channels
 __global__ __launch_bounds__(256) void k_vit_patchify(const uint8_t* __restrict__ bgr, int n, int h, int w, int64_t row_stride,
@@ -86,15 +66,6 @@ __global__ __launch_bounds__(256) void k_vit_patchify(const uint8_t* __restrict_
         const float v = top + (bot - top) * fy;
         A[blocked_index(row, c * kPatch * kPatch + k0, kDim)] = f32_to_bf16((v * (1.f / 255.f) - mean[c]) * istd[c]);
     }
-}
-
-constexpr int BKH = 32;                                     // a staging unit ("half stage") is 32 deep in K
-constexpr int kStages = 4;                                  // ring: kStages - 1 half stages in flight beside the one being read
-                                                            // (5 = all 160 KiB of LDS measured no faster than 4)
-
-__device__ __forceinline__ bf16x8 frag(const char* lds_tile, int row, int chunk)
-{
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + ((chunk ^ swz((row >> 2) & 3)) << 4));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

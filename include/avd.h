@@ -139,6 +139,27 @@ int avd_vit_set_weights(avd_ctx* ctx, const uint16_t* weight_bf16, const float* 
 int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride,
                         int64_t frame_stride, void* tokens, int tokens_mem, int tokens_bf16, int timing_reps, float* gemm_ms);
 
+/* CNN extension (build-defined: the reference has no learned model; BASELINE.json's north_star
+ * names a "CNN (ResNet-50-style) forward" on the matrix cores).  Never part of ai_score / timeline.  Topology: 7x7/2
+ * stem of 64 channels + ReLU, 3x3/2 max pool, bottleneck stages [3, 4, 6, 3] of widths 64/128/256/512 (x4 out, the stride
+ * on the 3x3 convolution, projection shortcut in the first block of a stage), global average pool, linear 2048 -> 1000;
+ * batch norm folded into weights + bias; bf16 weights and activations, f32 accumulation.
+ * avd_cnn_param_counts: elements of the flat parameter arrays.  avd_cnn_set_weights (host pointers, copied): weights =
+ * bf16 bits, convolutions in forward order (stem; per block conv1 1x1, conv2 3x3, conv3 1x1, then the projection shortcut
+ * where there is one), each [cout][kh][kw][cin], then the linear layer [1000][2048]; biases f32 in the same order.
+ * avd_cnn_forward: each BGR frame is resized to 224x224 and normalised as in avd_vit_patch_embed; logits: host float
+ * [n][1000].  If timing_reps > 0 and forward_ms != NULL the whole forward pass (input conversion to logits, 58 launches)
+ * is run timing_reps more times between two HIP events and its mean duration is returned (bench hook).
+ * avd_cnn_conv: ONE convolution layer on host tensors (test entry): x NHWC bf16 [n][hin][win][cin], w [cout][k][k][cin],
+ * bias f32[cout], optional residual NHWC [n][hout][wout][cout] added before the optional ReLU, y NHWC bf16; pad = k / 2;
+ * cin % 32 == 0, cout % 64 == 0, ksize 1 or 3, stride 1 or 2. */
+int avd_cnn_param_counts(size_t* n_weights, size_t* n_biases);
+int avd_cnn_set_weights(avd_ctx* ctx, const uint16_t* weights_bf16, size_t n_weights, const float* biases, size_t n_biases);
+int avd_cnn_forward(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
+                    float* logits, int timing_reps, float* forward_ms);
+int avd_cnn_conv(avd_ctx* ctx, const uint16_t* x, int n, int hin, int win, int cin, const uint16_t* w, const float* bias,
+                 int cout, int ksize, int stride, int relu, const uint16_t* residual, uint16_t* y);
+
 /* Audio analyzer: the per-window loop of reference app/analyzers/audio.py:40-61 for every window of a
  * mono float32 waveform at once.  wav: n samples (host or device); win: samples per window (the reference uses
  * int(sr * 0.5) = 8000 at 16 kHz; at most 8192); windows: host array of ceil(n / win) records, filled in order (the
