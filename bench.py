@@ -179,7 +179,7 @@ def main():
                     help="processes of the clip-parallel CPU baseline (capped at the host's cores; 1 = single thread only)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
-    ap.add_argument("--no-vit", action="store_true", help="skip the ViT patch-embed MFMA measurement (an extension, reported apart)")
+    ap.add_argument("--no-vit", action="store_true", help="skip the extensions reported apart (ViT patch-embed GEMM, CNN forward, audio analyzer)")
     ap.add_argument("--pcie", action="store_true", help="accepted for compatibility (the PCIe-inclusive figures are on by default)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="clips in flight per GPU, each on its own avd context / stream / workspace / input copy.  3 (default) = "
@@ -361,6 +361,18 @@ def main():
                "checksum": float(tok32[0, 0, :8].sum().item())}
         del big, tok, tok32
 
+    # CNN extension (build-defined, NOT part of `value`): ResNet-50-style forward of the clip's frames
+    cnn = None
+    if not args.no_vit and world == 1:
+        from avd_hip import cnn as host_cnn
+        wts, bss = host_cnn.seeded_parameters(0)
+        ctxs[0].cnn_set_weights(wts, bss)
+        ctxs[0].cnn_forward(frames[0], timing_reps=1)
+        logits, fwd_ms = ctxs[0].cnn_forward(frames[0], timing_reps=5)
+        cnn = {"frames": int(frames[0].shape[0]), "forward_ms": fwd_ms, "macs_per_frame": host_cnn.macs_per_frame(),
+               "top1_head": [int(v) for v in logits[:3].argmax(axis=1)]}
+        del wts, bss
+
     # audio analyzer, reported apart: the clip's 60 s sound track as 120 half-second windows
     audio = None
     if not args.no_vit and world == 1:
@@ -464,6 +476,18 @@ def main():
                 "M": mm, "N": 768, "K": 768, "flops_per_launch": fl, "avg_launch_ms": round(vit["gemm_ms"], 4),
                 "frames_per_launch": vit["frames"], "patchify_plus_call_overhead_ms": round(vit["whole_call_ms"], 3),
                 "timed": "20 launches between two HIP events on the library's stream, patches resident in HBM"}
+        if cnn is not None:
+            fl = 2.0 * cnn["macs_per_frame"] * cnn["frames"]
+            tf = fl / (cnn["forward_ms"] * 1e-3) / 1e12
+            out["mfma_cnn_forward"] = {
+                "kernel": "k_conv_bf16 x 53 (ResNet-50-style forward: every convolution one implicit GEMM, the activation operand gathered by "
+                          "LDS-DMA from blocked + swizzled bf16 activations, bias / residual / ReLU fused) + input, stem im2col, pooling, linear",
+                "extension": "no reference counterpart (the reference has no learned model); seeded random weights; not part of value / ai_score",
+                "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                "frames_per_forward": cnn["frames"], "gmac_per_frame": round(cnn["macs_per_frame"] / 1e9, 3),
+                "forward_ms": round(cnn["forward_ms"], 3), "frames_per_s": round(cnn["frames"] / (cnn["forward_ms"] * 1e-3), 1),
+                "launches_per_forward": 58, "top1_head": cnn["top1_head"],
+                "timed": "5 whole forward passes (BGR frames in HBM to logits) between two HIP events on the library's stream"}
         if audio is not None:
             out["audio_analyzer"] = {
                 "what": "avd_audio_features: RMS / zero crossings / Hann + direct 8000-point real DFT in double / flatness, roll-off, centroid "
