@@ -49,7 +49,7 @@ void free_ws(Workspace& ws)
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
-    F(ws.d_cnn_w); F(ws.d_cnn_b); F(ws.d_cnn_col); F(ws.d_cnn_img); F(ws.d_cnn_pool); F(ws.d_cnn_logits);
+    F(ws.d_cnn_w); F(ws.d_cnn_b); F(ws.d_cnn_img); F(ws.d_cnn_pool); F(ws.d_cnn_logits);
     for (int i = 0; i < 4; i++) F(ws.d_cnn_act[i]);
     if (ws.h_rec) (void)hipHostFree(ws.h_rec);
     ws = Workspace{};

@@ -15,7 +15,8 @@
 //  * the weight operand [cout][K = taps * cin] is re-tiled once on upload: an LDS-DMA instruction copies one KiB block;
 //  * the activation operand is GATHERED by the LDS-DMA itself: lane -> (tile row, 16-byte chunk), so a lane's source
 //    address is "the 8 channels I need of the input pixel this output pixel sees through tap (dy, dx)"; taps that fall
-//    outside the image read the zero page.  No im2col matrix is ever written (the 3-channel stem excepted);
+//    outside the image read the zero page.  No im2col matrix is ever written -- the 7x7 stem gathers pixel pairs from a
+//    zero-bordered copy of the input image instead (MODE 1 below);
 //  * the epilogue adds bias (+ the residual, read in the same layout), applies ReLU, rounds to bf16 and stores 16 bytes
 //    per lane straight into the blocked layout of the NEXT layer's operand.
 // Tile: 256 pixels x (64 | 128 | 256) output channels per 512-thread workgroup, K in half stages of 32, ring of four half
@@ -31,6 +32,7 @@ using namespace avd_mfma;
 
 constexpr int kSide = 224;
 constexpr int kZeroPage = 512;                  // elements (1 KiB) of zeros in front of every activation
+constexpr int kImgSide = 232;                   // the stem reads a 224 x 224 image with a zero border: pixel (y, x) at (y + 3, x + 3)
 
 struct ConvGeom {
     int hin, win, cin, hout, wout, cout, ksize, stride, pad;
@@ -41,16 +43,21 @@ struct ConvGeom {
 
 #define AVD_WAIT_VMC(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int WAVES_M, int TI>
+// MODE 0: the activation operand is a blocked activation, gathered per tap.  MODE 1 (the stem): the operand is the
+// zero-bordered 224 x 224 input image [frame][232][232][4 channels, the fourth zero]; half stage ky holds the 8 x 4 = 32
+// (kx, c) values of kernel row ky (kx = 7 and c = 3 carry zero weights), i.e. chunk j of a row = the two pixels
+// (2 ox + 2 j, 2 ox + 2 j + 1) of image row 2 oy + ky in border coordinates: 16 contiguous, 16-byte aligned bytes.
+template <int BM, int WAVES_M, int TI, int MODE>
 __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                   const float* __restrict__ bias, const uint16_t* __restrict__ R,
                                                   uint16_t* __restrict__ Y, ConvGeom g, int relu)
 {
-    constexpr int WAVES_N = 8 / WAVES_M, TJ = 4, BM = 256, BN = WAVES_N * 64;
-    static_assert(WAVES_M * TI * 16 == BM, "a workgroup covers 256 output pixels");
+    constexpr int WAVES_N = 8 / WAVES_M, TJ = 4, BN = WAVES_N * 64;
+    static_assert(WAVES_M * TI * 16 == BM && (BM == 256 || BM == 128), "a workgroup covers 256 or 128 output pixels");
+    constexpr int RA = BM / 8, QA = RA / 16;               // activation rows / LDS-DMA instructions per wave and half stage
     constexpr int RB = BN / 8;                              // weight rows a wave stages per half stage: 32, 16 or 8
     constexpr int QB = (RB + 15) / 16;
-    constexpr int P = 2 + QB;                               // LDS-DMA instructions per wave and half stage
+    constexpr int P = QA + QB;                              // LDS-DMA instructions per wave and half stage
     constexpr int HALF_A = BM * 64, HALF_B = BN * 64, STAGE = HALF_A + HALF_B;
     extern __shared__ __align__(16) char lds[];            // ring of four half stages [A | B]
     const int lane = threadIdx.x & 63;
@@ -63,19 +70,24 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
     if (lid >= total) return;
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
-    // ---- the two activation rows this lane gathers per half stage (instruction q: tile row wave * 32 + q * 16 + lane / 4)
-    int gy[2], gx[2], gb[2], cw[2];
-    bool gv[2];
+    // ---- the activation rows this lane gathers per half stage (instruction q: tile row wave * RA + q * 16 + lane / 4)
+    int gy[QA], gx[QA], gb[QA], cw[QA];
+    bool gv[QA];
     const int hw = g.hout * g.wout;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int r = wave * 32 + q * 16 + (lane >> 2), m = m0 + r;
+    for (int q = 0; q < QA; q++) {
+        const int r = wave * RA + q * 16 + (lane >> 2), m = m0 + r;
         gv[q] = m < g.m_out;
         const int img = m / hw, rem = m - img * hw, oy = rem / g.wout, ox = rem - oy * g.wout;
-        gy[q] = oy * g.stride - g.pad;
-        gx[q] = ox * g.stride - g.pad;
-        gb[q] = img * g.hin * g.win;
         cw[q] = (lane & 3) ^ swz((r >> 2) & 3);             // the chunk that belongs in this lane's LDS slot
+        if (MODE == 1) {                                     // byte offset of pixel (2 oy, 2 ox + 2 chunk) of the bordered image
+            gb[q] = gv[q] ? ((img * kImgSide + 2 * oy) * kImgSide + 2 * ox + 2 * cw[q]) * 8 : 0;
+            gy[q] = gx[q] = 0;
+        } else {
+            gy[q] = oy * g.stride - g.pad;
+            gx[q] = ox * g.stride - g.pad;
+            gb[q] = img * g.hin * g.win;
+        }
     }
     unsigned vob[QB];
 #pragma unroll
@@ -88,15 +100,20 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
     auto issue = [&](int hs) __attribute__((always_inline)) {
         char* st = lds + (hs & 3) * STAGE;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int yi = gy[q] + is_dy, xi = gx[q] + is_dx;
-            const bool ok = gv[q] && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win;
-            const int rin = gb[q] + yi * g.win + xi;
-            unsigned off = (unsigned)(kZeroPage * 2) + (unsigned)((rin >> 4) * g.cpb + is_cb) * 1024u + (unsigned)((rin & 15) * 64) +
-                           (unsigned)((cw[q] ^ swz((rin >> 2) & 3)) << 4);
-            off = ok ? off : (unsigned)(lane * 16);           // outside the image (or past the last pixel): the zero page
+        for (int q = 0; q < QA; q++) {
+            unsigned off;
+            if (MODE == 1) {
+                off = (unsigned)(gb[q] + hs * (kImgSide * 8));    // kernel row ky = hs: one image row down
+            } else {
+                const int yi = gy[q] + is_dy, xi = gx[q] + is_dx;
+                const bool ok = gv[q] && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win;
+                const int rin = gb[q] + yi * g.win + xi;
+                off = (unsigned)(kZeroPage * 2) + (unsigned)((rin >> 4) * g.cpb + is_cb) * 1024u + (unsigned)((rin & 15) * 64) +
+                      (unsigned)((cw[q] ^ swz((rin >> 2) & 3)) << 4);
+                off = ok ? off : (unsigned)(lane * 16);       // outside the image (or past the last pixel): the zero page
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
-                                             (__attribute__((address_space(3))) void*)(st + (wave * 32 + q * 16) * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + (wave * RA + q * 16) * 64), 16, 0, 0);
         }
         const char* wb = reinterpret_cast<const char*>(Wt + ((int64_t)(n0 >> 4) * g.nh + hs) * 512);
 #pragma unroll
@@ -186,7 +203,8 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
 }
 
 // BGR uint8 frame -> 224 x 224 (float bilinear taps, cv2's INTER_LINEAR centre mapping), RGB, (x / 255 - mean) / std,
-// bf16: img[frame * 224 * 224 + y * 224 + x][4] (fourth channel zero).  Same arithmetic as k_vit_patchify.
+// bf16: img[frame][y + 3][x + 3][4] of the zero-bordered 232 x 232 image (fourth channel zero; the border is cleared once,
+// when the buffer is allocated).  Same arithmetic as k_vit_patchify.
 __global__ __launch_bounds__(256) void k_cnn_input(const uint8_t* __restrict__ bgr, int n, int h, int w, int64_t row_stride,
                                                   int64_t frame_stride, uint16_t* __restrict__ img)
 {
@@ -217,35 +235,7 @@ __global__ __launch_bounds__(256) void k_cnn_input(const uint8_t* __restrict__ b
     uint2 pk;
     pk.x = v4[0] | ((unsigned)v4[1] << 16);
     pk.y = v4[2];
-    reinterpret_cast<uint2*>(img)[gid] = pk;
-}
-
-// im2col of the 7x7/2 (pad 3) stem: row = (frame, oy, ox) of the 112 x 112 output, k = (ky * 7 + kx) * 3 + c for k < 147,
-// zero up to 160; one thread = 8 consecutive k of one row = one 16-byte chunk of the blocked operand
-__global__ __launch_bounds__(256) void k_stem_im2col(const uint16_t* __restrict__ img, int n, uint16_t* __restrict__ A)
-{
-    constexpr int HO = 112, K = 160;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (int64_t)n * HO * HO * (K / 8)) return;
-    const int c8 = (int)(gid % (K / 8));
-    const int m = (int)(gid / (K / 8));
-    const int f = m / (HO * HO), rem = m - f * HO * HO, oy = rem / HO, ox = rem - oy * HO;
-    unsigned short v[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int k = c8 * 8 + e;
-        unsigned short val = 0;
-        if (k < 147) {
-            const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
-            const int yi = oy * 2 - 3 + ky, xi = ox * 2 - 3 + kx;
-            if ((unsigned)yi < (unsigned)kSide && (unsigned)xi < (unsigned)kSide) val = img[((int64_t)(f * kSide + yi) * kSide + xi) * 4 + c];
-        }
-        v[e] = val;
-    }
-    uint4 pk;
-    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
-    pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
-    *reinterpret_cast<uint4*>(A + kZeroPage + blocked_index(m, c8 * 8, K)) = pk;
+    reinterpret_cast<uint2*>(img)[((int64_t)f * kImgSide + y + 3) * kImgSide + x + 3] = pk;
 }
 
 __device__ __forceinline__ unsigned max_bf16x2(unsigned a, unsigned b)     // inputs are >= 0 (after a ReLU): integer order = value order
@@ -296,18 +286,28 @@ __global__ __launch_bounds__(256) void k_avgpool(const uint16_t* __restrict__ X,
     for (int e = 0; e < 8; e++) out[(int64_t)f * c + c8 * 8 + e] = s[e] * inv;
 }
 
-// logits[f][o] = pooled[f][:] . W[o][:] + b[o]; one wave per output (lane-strided k, then a butterfly sum)
+// logits[f][o] = pooled[f][:] . W[o][:] + b[o]; one wave per (output, group of 8 frames): the weight row (k = 2048: 32
+// values per lane) stays in registers, the pooled features come from L2
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const uint16_t* __restrict__ W, const float* __restrict__ b,
-                                               int n, int k, int nout, float* __restrict__ y)
+                                               int n, int nout, float* __restrict__ y)
 {
+    constexpr int K = 2048, FG = 8;
+    const int groups = (n + FG - 1) / FG;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wid >= n * nout) return;
-    const int f = wid / nout, o = wid - f * nout;
-    float s = 0.f;
-    for (int i = lane; i < k; i += 64) s = __builtin_fmaf(x[(int64_t)f * k + i], bf16_to_f32(W[(int64_t)o * k + i]), s);
+    if (wid >= groups * nout) return;
+    const int o = wid % nout, f0 = (wid / nout) * FG;
+    float wr[K / 64];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane == 0) y[wid] = s + b[o];
+    for (int i = 0; i < K / 64; i++) wr[i] = bf16_to_f32(W[(int64_t)o * K + i * 64 + lane]);
+    const float bo = b[o];
+    for (int f = f0; f < f0 + FG && f < n; f++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < K / 64; i++) s = __builtin_fmaf(x[(int64_t)f * K + i * 64 + lane], wr[i], s);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) y[(int64_t)f * nout + o] = s + bo;
+    }
 }
 
 // ---- network description -----------------------------------------------------------------------------------------
@@ -345,31 +345,36 @@ struct Net {
 };
 const Net& net() { static const Net n; return n; }
 
-int k_padded(const Layer& l) { return l.ksize == 7 ? 160 : l.ksize * l.ksize * l.cin; }   // the stem's 147 taps are padded to 160
+int k_padded(const Layer& l) { return l.ksize == 7 ? 7 * 8 * 4 : l.ksize * l.ksize * l.cin; }   // the stem: [7 ky][8 kx][4 c], kx = 7 and c = 3 zero
 
+// stem == true: x is the bordered input image, (hin, win, cin, ksize, stride) describe the 7x7/2 convolution
 int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res, uint16_t* y, int n, int hin,
-                int win, int cin, int cout, int ksize, int stride, int relu)
+                int win, int cin, int cout, int ksize, int stride, int relu, bool stem = false)
 {
     ConvGeom g;
     g.hin = hin; g.win = win; g.cin = cin; g.cout = cout; g.ksize = ksize; g.stride = stride; g.pad = ksize / 2;
     g.hout = (hin + 2 * g.pad - ksize) / stride + 1;
     g.wout = (win + 2 * g.pad - ksize) / stride + 1;
     g.m_out = n * g.hout * g.wout;
-    g.cpb = cin / 32;
-    g.nh = ksize * ksize * g.cpb;
-    if (cin % 32 || cout % 64 || (ksize != 1 && ksize != 3)) { ctx->err = "conv: cin % 32, cout % 64, ksize 1 or 3"; return AVD_ERR_ARG; }
-    const int tiles_m = (g.m_out + 255) / 256;
-    auto go = [&](auto kern, int bn) -> int {
-        const int total = tiles_m * (cout / bn), grid = (total + 7) / 8 * 8;
-        const size_t lds = 4 * (size_t)(256 * 64 + bn * 64);
+    g.cpb = stem ? 1 : cin / 32;
+    g.nh = stem ? 7 : ksize * ksize * g.cpb;
+    if (!stem && (cin % 32 || cout % 64 || (ksize != 1 && ksize != 3))) { ctx->err = "conv: cin % 32, cout % 64, ksize 1 or 3"; return AVD_ERR_ARG; }
+    auto go = [&](auto kern, int bm, int bn) -> int {
+        const int total = ((g.m_out + bm - 1) / bm) * (cout / bn), grid = (total + 7) / 8 * 8;
+        const size_t lds = 4 * (size_t)(bm * 64 + bn * 64);
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, x, w, bias, res, y, g, relu);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
-    if (cout % 256 == 0) return go(k_conv_bf16<2, 8>, 256);
-    if (cout % 128 == 0) return go(k_conv_bf16<4, 4>, 128);
-    return go(k_conv_bf16<8, 2>, 64);
+    if (stem) return go(k_conv_bf16<256, 8, 2, 1>, 256, 64);
+    // 256-pixel tiles unless they leave most of the chip idle (the 14 x 14 and 7 x 7 stages): then 128 x 128 tiles
+    const int bn_big = cout % 256 == 0 ? 256 : cout % 128 == 0 ? 128 : 64;
+    const int wgs_big = ((g.m_out + 255) / 256) * (cout / bn_big);
+    if (cout % 128 == 0 && wgs_big < ctx->num_cus * 3 / 2) return go(k_conv_bf16<128, 4, 2, 0>, 128, 128);
+    if (bn_big == 256) return go(k_conv_bf16<256, 2, 8, 0>, 256, 256);
+    if (bn_big == 128) return go(k_conv_bf16<256, 4, 4, 0>, 256, 128);
+    return go(k_conv_bf16<256, 8, 2, 0>, 256, 64);
 }
 
 size_t act_elems(size_t rows, int c) { return kZeroPage + (rows + 255) / 256 * 256 * (size_t)c; }
@@ -392,10 +397,12 @@ int cnn_set_weights(avd_ctx* ctx, const uint16_t* w, const float* b)
     for (const Layer& l : nt.convs) {
         const int K = k_padded(l), kin = l.ksize * l.ksize * l.cin;
         const uint16_t* src = w + l.w_off;
-        if (K != kin) {                                      // the stem: pad every output channel's 147 taps to 160
+        if (K != kin) {                                      // the stem: [cout][7][7][3] -> [cout][7 ky][8 kx][4 c], the extra taps zero
             tmp.assign((size_t)l.cout * K, 0);
             for (int o = 0; o < l.cout; o++)
-                for (int k = 0; k < kin; k++) tmp[(size_t)o * K + k] = src[(size_t)o * kin + k];
+                for (int ky = 0; ky < 7; ky++)
+                    for (int kx = 0; kx < 7; kx++)
+                        for (int c = 0; c < 3; c++) tmp[(size_t)o * K + (ky * 8 + kx) * 4 + c] = src[(size_t)o * kin + (ky * 7 + kx) * 3 + c];
             src = tmp.data();
         }
         gemm_block_operand(src, host.data() + off, l.cout, K);
@@ -412,7 +419,7 @@ int cnn_set_weights(avd_ctx* ctx, const uint16_t* w, const float* b)
     return AVD_OK;
 }
 
-// activation scratch for n frames: the stem's im2col operand, four rotating activations, the 224 x 224 input, pooled features
+// activation scratch for n frames: four rotating activations, the zero-bordered 224 x 224 input, pooled features, logits
 int cnn_reserve(avd_ctx* ctx, int n)
 {
     Workspace& ws = ctx->ws;
@@ -422,9 +429,8 @@ int cnn_reserve(avd_ctx* ctx, int n)
         if (int e = dev_alloc(ctx, ws.d_cnn_act[i], act)) return e;
         HIP_TRY(ctx, hipMemsetAsync(ws.d_cnn_act[i], 0, kZeroPage * sizeof(uint16_t), ctx->stream));
     }
-    if (int e = dev_alloc(ctx, ws.d_cnn_col, act_elems((size_t)n * 112 * 112, 160))) return e;
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_cnn_col, 0, kZeroPage * sizeof(uint16_t), ctx->stream));
-    if (int e = dev_alloc(ctx, ws.d_cnn_img, (size_t)n * kSide * kSide * 4)) return e;
+    if (int e = dev_alloc(ctx, ws.d_cnn_img, (size_t)n * kImgSide * kImgSide * 4)) return e;
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_cnn_img, 0, (size_t)n * kImgSide * kImgSide * 4 * sizeof(uint16_t), ctx->stream));   // the zero border
     if (int e = dev_alloc(ctx, ws.d_cnn_pool, (size_t)n * 2048)) return e;
     if (int e = dev_alloc(ctx, ws.d_cnn_logits, (size_t)n * 1000)) return e;
     ws.cnn_frames = n;
@@ -438,13 +444,11 @@ int launch_cnn_forward(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, 
     Workspace& ws = ctx->ws;
     const int64_t px = (int64_t)n * kSide * kSide;
     hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, n, h, w, row_stride, frame_stride, ws.d_cnn_img);
-    const int64_t chunks = (int64_t)n * 112 * 112 * 20;
-    hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_img, n, ws.d_cnn_col);
     size_t li = 0;
     auto wptr = [&](size_t i) { return ws.d_cnn_w + ws.cnn_w_off[i]; };
     auto bptr = [&](size_t i) { return ws.d_cnn_b + nt.convs[i].b_off; };
-    // the stem as a 1x1 convolution over its im2col operand (K = 160)
-    if (int e = launch_conv(ctx, ws.d_cnn_col, wptr(0), bptr(0), nullptr, ws.d_cnn_act[0], n, 112, 112, 160, 64, 1, 1, 1)) return e;
+    // the stem gathers straight from the bordered image (one half stage per kernel row)
+    if (int e = launch_conv(ctx, ws.d_cnn_img, wptr(0), bptr(0), nullptr, ws.d_cnn_act[0], n, kSide, kSide, 3, 64, 7, 2, 1, true)) return e;
     li = 1;
     const int64_t pooled = (int64_t)n * 56 * 56 * 8;
     hipLaunchKernelGGL(k_maxpool3, dim3((unsigned)((pooled + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_act[0], n, 112, 112, 64, ws.d_cnn_act[1]);
@@ -471,8 +475,8 @@ int launch_cnn_forward(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, 
         }
     }
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n * 256 + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_act[cur], n, 49, 2048, ws.d_cnn_pool);
-    hipLaunchKernelGGL(k_linear, dim3((unsigned)((n * 1000 + 3) / 4)), dim3(256), 0, ctx->stream, ws.d_cnn_pool, ws.d_cnn_w + ws.cnn_fc_off,
-                       ws.d_cnn_b + nt.fc_b, n, 2048, 1000, ws.d_cnn_logits);
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)(((n + 7) / 8 * 1000 + 3) / 4)), dim3(256), 0, ctx->stream, ws.d_cnn_pool, ws.d_cnn_w + ws.cnn_fc_off,
+                       ws.d_cnn_b + nt.fc_b, n, 1000, ws.d_cnn_logits);
     HIP_TRY(ctx, hipGetLastError());
     return AVD_OK;
 }

@@ -122,7 +122,7 @@ struct Workspace {
     // CNN extension (avd_cnn.hip): blocked conv weights + linear layer, biases, activation scratch for cnn_frames frames
     uint16_t* d_cnn_w = nullptr; float* d_cnn_b = nullptr;
     std::vector<size_t> cnn_w_off; size_t cnn_fc_off = 0;
-    uint16_t* d_cnn_act[4] = {}; uint16_t* d_cnn_col = nullptr; uint16_t* d_cnn_img = nullptr;
+    uint16_t* d_cnn_act[4] = {}; uint16_t* d_cnn_img = nullptr;
     float* d_cnn_pool = nullptr; float* d_cnn_logits = nullptr; int cnn_frames = 0;
 };
 
