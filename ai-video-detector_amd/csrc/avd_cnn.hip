@@ -361,17 +361,23 @@ int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float*
     if (!stem && (cin % 32 || cout % 64 || (ksize != 1 && ksize != 3))) { ctx->err = "conv: cin % 32, cout % 64, ksize 1 or 3"; return AVD_ERR_ARG; }
     auto go = [&](auto kern, int bm, int bn) -> int {
         const int total = ((g.m_out + bm - 1) / bm) * (cout / bn), grid = (total + 7) / 8 * 8;
-        const size_t lds = 4 * (size_t)(bm * 64 + bn * 64);
+        const size_t lds = (size_t)(g.nh < 4 ? g.nh : 4) * (size_t)(bm * 64 + bn * 64);   // short K: fewer ring slots, more workgroups per CU
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, x, w, bias, res, y, g, relu);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
     if (stem) return go(k_conv_bf16<256, 8, 2, 1>, 256, 64);
-    // 256-pixel tiles unless they leave most of the chip idle (the 14 x 14 and 7 x 7 stages): then 128 x 128 tiles
+    // 256-pixel tiles for the long-K layers that fill the chip.  128 x 128 tiles (74 registers, 16 KiB per ring slot: several
+    // workgroups per CU) where 256-pixel tiles would leave most of the chip idle (the 14 x 14 and 7 x 7 stages), and for the
+    // short-K 1x1 layers, which move bytes rather than multiply: there the time goes to load / store latency, and
+    // co-resident workgroups are what hides it.
+    static const int force = [] { const char* e = std::getenv("AVD_CNN_TILES"); return e ? std::atoi(e) : 0; }();   // 1: always 256, 2: always 128 x 128
     const int bn_big = cout % 256 == 0 ? 256 : cout % 128 == 0 ? 128 : 64;
     const int wgs_big = ((g.m_out + 255) / 256) * (cout / bn_big);
-    if (cout % 128 == 0 && wgs_big < ctx->num_cus * 3 / 2) return go(k_conv_bf16<128, 4, 2, 0>, 128, 128);
+    const bool small_ok = cout % 128 == 0;
+    const bool want_small = wgs_big < ctx->num_cus * 3 / 2 || g.nh <= 8;
+    if (small_ok && force != 1 && (want_small || force == 2)) return go(k_conv_bf16<128, 4, 2, 0>, 128, 128);
     if (bn_big == 256) return go(k_conv_bf16<256, 2, 8, 0>, 256, 256);
     if (bn_big == 128) return go(k_conv_bf16<256, 4, 4, 0>, 256, 128);
     return go(k_conv_bf16<256, 8, 2, 0>, 256, 64);
