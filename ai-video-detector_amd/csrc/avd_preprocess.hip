@@ -481,20 +481,22 @@ __device__ __forceinline__ int clip8(int v) { return min(max(v, 0), 255); }
 
 // chroma part of the three table lookups of one U,V pair: c0 + off * cy per channel
 struct ChromaTerms { int r, g, b; };
+// every product below has operands inside 24 bits (8-bit samples, 17-bit coefficients, table indices of a few hundred):
+// __mul24 / __umul24 are full-rate instructions where a 32-bit multiply is quarter rate
 __device__ __forceinline__ ChromaTerms chroma_terms(int U, int V, const YuvConsts& k)
 {
     ChromaTerms t;
-    t.r = k.c0 + (((V * k.crv) >> 16) + k.kr) * k.cy;
-    t.b = k.c0 + (((U * k.cbu) >> 16) + k.kb) * k.cy;
-    t.g = k.c0 + (((U * k.cgu) >> 16) + ((V * k.cgv) >> 16) + k.kg) * k.cy;
+    t.r = k.c0 + __mul24((__mul24(V, k.crv) >> 16) + k.kr, k.cy);
+    t.b = k.c0 + __mul24((__mul24(U, k.cbu) >> 16) + k.kb, k.cy);
+    t.g = k.c0 + __mul24((__mul24(U, k.cgu) >> 16) + (__mul24(V, k.cgv) >> 16) + k.kg, k.cy);
     return t;
 }
 
 __device__ __forceinline__ unsigned gray_from_yuv(int Y, const ChromaTerms& t, int cy)
 {
-    const int yl = Y * cy;
+    const int yl = __mul24(Y, cy);
     const unsigned B = (unsigned)clip8((yl + t.b) >> 16), G = (unsigned)clip8((yl + t.g) >> 16), R = (unsigned)clip8((yl + t.r) >> 16);
-    return (B * 3735u + G * 19235u + R * 9798u + (1u << 14)) >> 15;
+    return (__umul24(B, 3735u) + __umul24(G, 19235u) + __umul24(R, 9798u) + (1u << 14)) >> 15;
 }
 
 // 4 luma bytes + 2 chroma pairs (U0 V0 U1 V1) -> 4 gray bytes
@@ -708,6 +710,8 @@ int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& n
                      (reinterpret_cast<uintptr_t>(nv.uv) % 16 == 0);
     const int grid = ((total + 7) / 8) * 8;
     const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
+    // (a register-staged variant in the style of k_preprocess_vec measured no faster: the kernel is bound by the
+    // conversion's integer arithmetic, not by how its loads are issued -- profiles/r02_experiments.md)
     ws.lap_waves = kThreads / 64;
     if (vec)
         hipLaunchKernelGGL(k_preprocess_nv12<true>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small,
