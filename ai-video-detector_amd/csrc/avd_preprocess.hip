@@ -494,8 +494,9 @@ __device__ __forceinline__ ChromaTerms chroma_terms(int U, int V, const YuvConst
 
 __device__ __forceinline__ unsigned gray_from_yuv(int Y, const ChromaTerms& t, int cy)
 {
-    const int yl = __mul24(Y, cy);
-    const unsigned B = (unsigned)clip8((yl + t.b) >> 16), G = (unsigned)clip8((yl + t.g) >> 16), R = (unsigned)clip8((yl + t.r) >> 16);
+    // Y * cy + term: one v_mad_i32_i24 per channel
+    const unsigned B = (unsigned)clip8((__mul24(Y, cy) + t.b) >> 16), G = (unsigned)clip8((__mul24(Y, cy) + t.g) >> 16),
+                   R = (unsigned)clip8((__mul24(Y, cy) + t.r) >> 16);
     return (__umul24(B, 3735u) + __umul24(G, 19235u) + __umul24(R, 9798u) + (1u << 14)) >> 15;
 }
 
@@ -527,17 +528,49 @@ __global__ __launch_bounds__(kThreads) void k_preprocess_nv12(const uint8_t* __r
     const uint8_t* cfr = nv.uv + (int64_t)f * nv.uv_frame_stride;
     const int trows = rows + 2;                            // tile row 0 = image row r0-1
     if (VEC) {
+        // one work item = one chroma row x one 16-pixel chunk: the eight chroma-term triples are formed once and serve the
+        // two luma rows that share them (they are 8.5 of the ~27 integer operations a pixel costs otherwise)
+        const int ylo = r0 - 1, yhi = r0 + rows;              // image rows of tile rows 0 and trows - 1, before reflection
+        const int ya = max(ylo, 0), yb = min(yhi, h - 1);      // the ones that exist
+        const int p0 = ya >> 1, np = (yb >> 1) - p0 + 1;
         const int chunks = w >> 4;
-        for (int it = tid; it < trows * chunks; it += kThreads) {
-            const int tr = it / chunks, c = it - tr * chunks;
-            const int y = reflect_once(r0 - 1 + tr, h);
-            const uint4 yy = *reinterpret_cast<const uint4*>(yfr + (int64_t)y * P.row_stride + c * 16);
-            const uint4 cc = *reinterpret_cast<const uint4*>(cfr + (int64_t)(y >> 1) * nv.uv_row_stride + c * 16);
-            uint4 g;
-            g.x = gray4_nv12(yy.x, cc.x, nv.k); g.y = gray4_nv12(yy.y, cc.y, nv.k);
-            g.z = gray4_nv12(yy.z, cc.z, nv.k); g.w = gray4_nv12(yy.w, cc.w, nv.k);
-            *reinterpret_cast<uint4*>(tile + tr * pitch + kPad + c * 16) = g;
+        for (int it = tid; it < np * chunks; it += kThreads) {
+            const int pr = it / chunks, c = it - pr * chunks, p = p0 + pr;
+            const uint4 cc = *reinterpret_cast<const uint4*>(cfr + (int64_t)p * nv.uv_row_stride + c * 16);
+            const unsigned cw[4] = {cc.x, cc.y, cc.z, cc.w};
+            ChromaTerms t[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[2 * j] = chroma_terms(cw[j] & 0xFF, (cw[j] >> 8) & 0xFF, nv.k);
+                t[2 * j + 1] = chroma_terms((cw[j] >> 16) & 0xFF, cw[j] >> 24, nv.k);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int y = 2 * p + s2;
+                if (y < ya || y > yb) continue;
+                const uint4 yy = *reinterpret_cast<const uint4*>(yfr + (int64_t)y * P.row_stride + c * 16);
+                const unsigned yw[4] = {yy.x, yy.y, yy.z, yy.w};
+                unsigned g[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#ifdef AVD_NV12_NOCONV      // timing experiment: no conversion arithmetic (results are wrong)
+                    g[j] = yw[j] ^ cw[j];
+#else
+                    g[j] = gray_from_yuv(yw[j] & 0xFF, t[2 * j], nv.k.cy) | (gray_from_yuv((yw[j] >> 8) & 0xFF, t[2 * j], nv.k.cy) << 8) |
+                           (gray_from_yuv((yw[j] >> 16) & 0xFF, t[2 * j + 1], nv.k.cy) << 16) | (gray_from_yuv(yw[j] >> 24, t[2 * j + 1], nv.k.cy) << 24);
+#endif
+                *reinterpret_cast<uint4*>(tile + (y - ylo) * pitch + kPad + c * 16) = make_uint4(g[0], g[1], g[2], g[3]);
+            }
         }
+        __syncthreads();
+        // BORDER_REFLECT_101 rows: image row -1 is row 1, row h is row h - 2 (both already in the tile)
+        if (ylo < 0)
+            for (int c = tid; c < chunks; c += kThreads)
+                *reinterpret_cast<uint4*>(tile + kPad + c * 16) = *reinterpret_cast<const uint4*>(tile + 2 * pitch + kPad + c * 16);
+        if (yhi > h - 1)
+            for (int c = tid; c < chunks; c += kThreads)
+                *reinterpret_cast<uint4*>(tile + (trows - 1) * pitch + kPad + c * 16) =
+                    *reinterpret_cast<const uint4*>(tile + (trows - 3) * pitch + kPad + c * 16);
     } else {
         for (int it = tid; it < trows * w; it += kThreads) {
             const int tr = it / w, x = it - tr * w;
