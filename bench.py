@@ -479,6 +479,13 @@ def main():
         if cnn is not None:
             fl = 2.0 * cnn["macs_per_frame"] * cnn["frames"]
             tf = fl / (cnn["forward_ms"] * 1e-3) / 1e12
+            cnn_traffic = None
+            try:
+                ext = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_extensions.json")))
+                if cnn["frames"] == 120:
+                    cnn_traffic = ext["cnn_forward_120_frames"]["hbm_bytes"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["mfma_cnn_forward"] = {
                 "kernel": "k_conv_bf16 x 53 (ResNet-50-style forward: every convolution one implicit GEMM, the activation operand gathered by "
                           "LDS-DMA from blocked + swizzled bf16 activations, bias / residual / ReLU fused; the 7x7 stem gathers pixel pairs from a zero-bordered input image) + input conversion, max / average pooling, linear",
@@ -487,6 +494,10 @@ def main():
                 "frames_per_forward": cnn["frames"], "gmac_per_frame": round(cnn["macs_per_frame"] / 1e9, 3),
                 "forward_ms": round(cnn["forward_ms"], 3), "frames_per_s": round(cnn["frames"] / (cnn["forward_ms"] * 1e-3), 1),
                 "launches_per_forward": 57, "top1_head": cnn["top1_head"],
+                "hbm_traffic_bytes_per_forward": cnn_traffic,
+                "hbm_gbps": None if cnn_traffic is None else round(cnn_traffic / (cnn["forward_ms"] * 1e-3) / 1e9, 1),
+                "hbm_note": "PMC traffic (profiles/r02_pmc_extensions.json, 120 frames): bf16 activations written and read once per layer are "
+                            "63 MB per frame -- a layer-by-layer forward is bound by this traffic (~1.5 ms per 120 frames at 5 TB/s), not by the matrix pipe",
                 "timed": "5 whole forward passes (BGR frames in HBM to logits) between two HIP events on the library's stream"}
         if audio is not None:
             out["audio_analyzer"] = {
