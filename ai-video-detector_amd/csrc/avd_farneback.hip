@@ -36,19 +36,31 @@ constexpr int S = AVD_SMALL;
 //   -> LDS float [rows][NC];  column pass (SymmColumnVec_32f order) + 2x2 mean -> I[f][dy][dx].
 // ---------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ small, int n,
-                                                const FbConsts* __restrict__ C, float* __restrict__ I)
+struct PyrGeo {
+    static constexpr int WL = S >> K;
+    static constexpr int NC = K == 0 ? S : 2 * WL;              // filtered columns per row
+    static constexpr int OFF = K == 0 ? 0 : (1 << K) / 2 - 1;
+    static constexpr int TR = 8;                                // output rows per workgroup
+    static constexpr int KS = K == 3 ? 19 : (K == 2 ? 9 : 3), HALF = KS / 2;
+    static constexpr int SROWS = K == 0 ? TR + 2 * HALF : ((TR - 1) << K) + 2 + 2 * HALF;   // source rows needed
+    static constexpr int PADX = 12, PS = S + 2 * PADX;          // source rows carry their reflected borders (HALF <= 9 < PADX, PADX % 4 == 0)
+    static constexpr int SRC_BYTES = SROWS * PS, LDS_BYTES = SRC_BYTES + SROWS * NC * 4;
+};
+constexpr int kPyrLds = PyrGeo<3>::LDS_BYTES > PyrGeo<2>::LDS_BYTES ? PyrGeo<3>::LDS_BYTES : PyrGeo<2>::LDS_BYTES;
+static_assert(kPyrLds >= PyrGeo<1>::LDS_BYTES && kPyrLds >= PyrGeo<0>::LDS_BYTES, "the coarse scales need the most LDS");
+
+// blk = frame * (WL / 8) + tile of this scale
+template <int K>
+__device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* __restrict__ small, const FbConsts* __restrict__ C,
+                                             float* __restrict__ I)
 {
-    constexpr int WL = S >> K;
-    constexpr int NC = K == 0 ? S : 2 * WL;              // filtered columns per row
-    constexpr int OFF = K == 0 ? 0 : (1 << K) / 2 - 1;
-    constexpr int TR = 8;                                // output rows per workgroup
-    constexpr int KS = K == 3 ? 19 : (K == 2 ? 9 : 3), HALF = KS / 2;
-    constexpr int SROWS = K == 0 ? TR + 2 * HALF : ((TR - 1) << K) + 2 + 2 * HALF;   // source rows needed
-    __shared__ __align__(16) uint8_t src[SROWS][S];
-    __shared__ float rowf[SROWS][NC];
+    using G = PyrGeo<K>;
+    constexpr int WL = G::WL, NC = G::NC, OFF = G::OFF, TR = G::TR, KS = G::KS, HALF = G::HALF, SROWS = G::SROWS;
+    constexpr int PADX = G::PADX, PS = G::PS;
+    uint8_t (*src)[PS] = reinterpret_cast<uint8_t (*)[PS]>(lds);
+    float (*rowf)[NC] = reinterpret_cast<float (*)[NC]>(lds + G::SRC_BYTES);
     const int tiles = WL / TR;
-    const int f = blockIdx.x / tiles, t = blockIdx.x - f * tiles;
+    const int f = blk / tiles, t = blk - f * tiles;
     const int tid = threadIdx.x;
     const int dy0 = t * TR;
     const int y_first = (K == 0 ? dy0 : (dy0 << K) + OFF) - HALF;        // first source row (may be < 0)
@@ -56,22 +68,42 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ sma
     for (int it = tid; it < SROWS * (S / 4); it += 256) {
         const int r = it / (S / 4), c4 = it - r * (S / 4);
         const int y = reflect101(y_first + r, S);
-        reinterpret_cast<unsigned*>(src[r])[c4] = reinterpret_cast<const unsigned*>(img + y * S)[c4];
+        reinterpret_cast<unsigned*>(src[r] + PADX)[c4] = reinterpret_cast<const unsigned*>(img + y * S)[c4];
+    }
+    // BORDER_REFLECT_101 columns, so that the taps below need no index arithmetic: x = -1 - i is x = 1 + i, x = S + i is S - 2 - i
+    for (int it = tid; it < SROWS * 2 * HALF; it += 256) {
+        const int r = it / (2 * HALF), i = it - r * (2 * HALF);
+        const uint8_t* g = img + reflect101(y_first + r, S) * S;
+        if (i < HALF) src[r][PADX - 1 - i] = g[1 + i];
+        else src[r][PADX + S + (i - HALF)] = g[S - 2 - (i - HALF)];
     }
     __syncthreads();
     const float* kx = C->gk[K];
     for (int it = tid; it < SROWS * NC; it += 256) {
         const int r = it / NC, j = it - r * NC;
         const int x = K == 0 ? j : ((j >> 1) << K) + OFF + (j & 1);
-        const uint8_t* row = src[r];
+        const uint8_t* row = src[r] + PADX;
         float v;
         if (KS == 3) {
-            const float l = (float)row[reflect101(x - 1, S)], c = (float)row[x], rr = (float)row[reflect101(x + 1, S)];
+            const float l = (float)row[x - 1], c = (float)row[x], rr = (float)row[x + 1];
             v = __builtin_fmaf(c, kx[1], (l + rr) * kx[0]);
         } else {
+            // the KS source bytes x - HALF .. x + HALF: aligned 32-bit LDS reads, one byte alignment of the window
+            // (v_alignbyte), then one v_cvt_f32_ubyteN per tap -- instead of a byte read and a reflected index per tap
+            constexpr int NW = (KS + 3) / 4;                         // aligned words of the window
+            const int base = PADX + x - HALF, sh = base & 3;
+            const unsigned* wp = reinterpret_cast<const unsigned*>(src[r] + (base & ~3));
+            unsigned d[NW + 1];
+#pragma unroll
+            for (int q = 0; q <= NW; q++) d[q] = wp[q];
             v = 0.f;
 #pragma unroll
-            for (int k = 0; k < KS; k++) v = __builtin_fmaf((float)row[reflect101(x - HALF + k, S)], kx[k], v);
+            for (int q = 0; q < NW; q++) {
+                const unsigned wv = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (q * 4 + e < KS) v = __builtin_fmaf((float)((wv >> (8 * e)) & 0xFFu), kx[q * 4 + e], v);
+            }
         }
         rowf[r][j] = v;
     }
@@ -98,62 +130,101 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ sma
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// FarnebackPolyExp (poly_n = 5): one workgroup per image row.  Vertical 11-tap pass in
-// float into LDS (3 moment planes, replicate border), horizontal pass with double
-// accumulators, output 5 interleaved coefficients R[y][x][c].
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(320) void k_polyexp(const float* __restrict__ I, int w, int h, int total,
-                                                const FbConsts* __restrict__ C, float* __restrict__ R)
+// the four scales of every frame in ONE launch (coarsest first: its workgroups do the most work): the small scales
+// alone cannot fill the chip (600 workgroups at 40 px for a 120-frame clip) and used to run one after the other
+__global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__ small, int n, const FbConsts* __restrict__ C,
+                                                    float* __restrict__ I0, float* __restrict__ I1, float* __restrict__ I2,
+                                                    float* __restrict__ I3)
 {
-    __shared__ float row[3][S + 10];
-    // consecutive rows read overlapping 11-row windows: give an XCD (one L2) a contiguous run of rows
-    // (the grid is padded to a multiple of 8; total = frames x rows)
-    const int per = gridDim.x >> 3, lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (lid >= total) return;
-    const int y = lid % h, f = lid / h;
-    const int x = threadIdx.x;
-    const float* img = I + (int64_t)f * w * h;
+    __shared__ __align__(16) char lds[kPyrLds];
+    const int n3 = n * (PyrGeo<3>::WL / 8), n2 = n * (PyrGeo<2>::WL / 8), n1 = n * (PyrGeo<1>::WL / 8);
+    int b = blockIdx.x;
+    if (b < n3) { pyramid_body<3>(lds, b, small, C, I3); return; }
+    b -= n3;
+    if (b < n2) { pyramid_body<2>(lds, b, small, C, I2); return; }
+    b -= n2;
+    if (b < n1) { pyramid_body<1>(lds, b, small, C, I1); return; }
+    pyramid_body<0>(lds, b - n1, small, C, I0);
+}
+
+// ---------------------------------------------------------------------------------------
+// FarnebackPolyExp (poly_n = 5), all four scales in ONE launch.  A 320-thread workgroup owns 320 / w consecutive image
+// rows of one frame (one row at 320 px, eight at 40 px: every lane has a pixel at every scale).  Vertical 11-tap pass in
+// float into LDS (3 moment planes, replicate border), horizontal pass with double accumulators, 5 interleaved
+// coefficients R[y][x][c] (cv2's own layout: the level kernel gathers a pixel's five coefficients and its right-hand
+// neighbour's as ten consecutive floats).  The workgroup's output is ONE contiguous span of 1600 floats: it is staged in
+// LDS and stored as 16-byte pieces (a lane's own five floats are 20 bytes apart from its neighbour's).
+// ---------------------------------------------------------------------------------------
+struct PolyPtrs { const float* I[AVD_FB_LEVELS]; float* R[AVD_FB_LEVELS]; };
+
+__global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const FbConsts* __restrict__ C)
+{
+    __shared__ float row[3][S + 80];                     // per sub-row: w + 10 entries (5 replicated on either side)
+    __shared__ __align__(16) float outb[S * 5];
+    // scale k: w = 320 >> k, rows per workgroup 1 << k, workgroups n * 320 / 4^k (padded to a multiple of 8: within a scale
+    // consecutive workgroups -- overlapping 11-row windows -- share an XCD)
+    int b = blockIdx.x, k = 0;
+    for (; k < AVD_FB_LEVELS; k++) {
+        const int cnt = ((n * (S >> (2 * k)) + 7) >> 3) << 3;
+        if (b < cnt) break;
+        b -= cnt;
+    }
+    if (k >= AVD_FB_LEVELS) return;
+    const int wgs = n * (S >> (2 * k));
+    const int per = ((wgs + 7) >> 3), lid = (b & 7) * per + (b >> 3);
+    if (lid >= wgs) return;
+    const int w = S >> k, h = w;
+    const int wgs_per_frame = h >> k;
+    const int f = lid / wgs_per_frame, y0 = (lid - f * wgs_per_frame) << k;
+    const int tid = threadIdx.x;
+    const int sr = tid / w, x = tid - sr * w;            // sub-row of this lane, column
+    const int y = y0 + sr;
+    const float* img = P.I[k] + (int64_t)f * w * h;
     const float* g = C->g + 5; const float* xg = C->xg + 5; const float* xxg = C->xxg + 5;
-    if (x < w) {
+    const int pitch = w + 10;
+    float* r0s = row[0] + sr * pitch; float* r1s = row[1] + sr * pitch; float* r2s = row[2] + sr * pitch;
+    {
         float t0 = img[y * w + x] * g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int k = 1; k <= 5; k++) {
-            const float a = img[max(y - k, 0) * w + x], b = img[min(y + k, h - 1) * w + x];
-            const float p = a + b;
-            t0 = t0 + g[k] * p;
-            t1 = t1 + xg[k] * (b - a);
-            t2 = t2 + xxg[k] * p;
+        for (int q = 1; q <= 5; q++) {
+            const float a = img[max(y - q, 0) * w + x], bb = img[min(y + q, h - 1) * w + x];
+            const float p = a + bb;
+            t0 = t0 + g[q] * p;
+            t1 = t1 + xg[q] * (bb - a);
+            t2 = t2 + xxg[q] * p;
         }
-        row[0][x + 5] = t0; row[1][x + 5] = t1; row[2][x + 5] = t2;
+        r0s[x + 5] = t0; r1s[x + 5] = t1; r2s[x + 5] = t2;
         if (x == 0)
-            for (int k = 0; k < 5; k++) { row[0][k] = t0; row[1][k] = t1; row[2][k] = t2; }
+            for (int q = 0; q < 5; q++) { r0s[q] = t0; r1s[q] = t1; r2s[q] = t2; }
         if (x == w - 1)
-            for (int k = 0; k < 5; k++) { row[0][w + 5 + k] = t0; row[1][w + 5 + k] = t1; row[2][w + 5 + k] = t2; }
+            for (int q = 0; q < 5; q++) { r0s[w + 5 + q] = t0; r1s[w + 5 + q] = t1; r2s[w + 5 + q] = t2; }
     }
     __syncthreads();
-    if (x >= w) return;
-    const float* r0 = row[0] + x + 5; const float* r1 = row[1] + x + 5; const float* r2 = row[2] + x + 5;
+    const float* r0 = r0s + x + 5; const float* r1 = r1s + x + 5; const float* r2 = r2s + x + 5;
     double b1 = (double)(r0[0] * g[0]), b2 = 0, b3 = (double)(r1[0] * g[0]), b4 = 0,
            b5 = (double)(r2[0] * g[0]), b6 = 0;
 #pragma unroll
-    for (int k = 1; k <= 5; k++) {
-        const double tg = (double)(r0[k] + r0[-k]);
-        b1 += tg * (double)g[k];
-        b4 += tg * (double)xxg[k];
-        b2 += (double)((r0[k] - r0[-k]) * xg[k]);
-        b3 += (double)((r1[k] + r1[-k]) * g[k]);
-        b6 += (double)((r1[k] - r1[-k]) * xg[k]);
-        b5 += (double)((r2[k] + r2[-k]) * g[k]);
+    for (int q = 1; q <= 5; q++) {
+        const double tg = (double)(r0[q] + r0[-q]);
+        b1 += tg * (double)g[q];
+        b4 += tg * (double)xxg[q];
+        b2 += (double)((r0[q] - r0[-q]) * xg[q]);
+        b3 += (double)((r1[q] + r1[-q]) * g[q]);
+        b6 += (double)((r1[q] - r1[-q]) * xg[q]);
+        b5 += (double)((r2[q] + r2[-q]) * g[q]);
     }
-    // interleaved [y][x][5] (cv2's own layout): k_uv gathers all five coefficients of a pixel and of
-    // its right-hand neighbour as ten consecutive floats
-    float* out = R + ((int64_t)f * w * h + y * w + x) * 5;
-    __builtin_nontemporal_store((float)(b3 * C->ig11), out + 0);
-    __builtin_nontemporal_store((float)(b2 * C->ig11), out + 1);
-    __builtin_nontemporal_store((float)(b1 * C->ig03 + b5 * C->ig33), out + 2);
-    __builtin_nontemporal_store((float)(b1 * C->ig03 + b4 * C->ig33), out + 3);
-    __builtin_nontemporal_store((float)(b6 * C->ig55), out + 4);
+    float* o = outb + tid * 5;                           // (sub-row, x) order = memory order of the workgroup's rows
+    o[0] = (float)(b3 * C->ig11);
+    o[1] = (float)(b2 * C->ig11);
+    o[2] = (float)(b1 * C->ig03 + b5 * C->ig33);
+    o[3] = (float)(b1 * C->ig03 + b4 * C->ig33);
+    o[4] = (float)(b6 * C->ig55);
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* dst = reinterpret_cast<f4*>(P.R[k] + ((int64_t)f * w * h + (int64_t)y0 * w) * 5);
+    const f4* srcv = reinterpret_cast<const f4*>(outb);
+    __builtin_nontemporal_store(srcv[tid], dst + tid);
+    if (tid < S * 5 / 4 - 320) __builtin_nontemporal_store(srcv[tid + 320], dst + tid + 320);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -800,13 +871,19 @@ inline void launch1d(void (*k)(A...), int64_t items, int block, hipStream_t s, A
     if (grid > 0) hipLaunchKernelGGL(k, dim3(grid), dim3(block), 0, s, args...);
 }
 
-template <int K>
-void pyramid_level(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int n)
+// Gaussian pyramid + polynomial expansion of n frames at all four scales: two launches
+void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int n)
 {
-    constexpr int WL = S >> K;
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
-    hipLaunchKernelGGL(k_pyramid<K>, dim3(n * (WL / 8)), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[K]);
-    hipLaunchKernelGGL(k_polyexp, dim3(8 * ((n * WL + 7) / 8)), dim3(320), 0, g.stream, g.pyr[K], WL, WL, n * WL, C, g.poly[K]);
+    const int wgs = n * (S / 8 + S / 16 + S / 32 + S / 64);
+    hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3]);
+    PolyPtrs P;
+    int grid = 0;
+    for (int k = 0; k < AVD_FB_LEVELS; k++) {
+        P.I[k] = g.pyr[k]; P.R[k] = g.poly[k];
+        grid += ((n * (S >> (2 * k)) + 7) >> 3) << 3;
+    }
+    hipLaunchKernelGGL(k_polyexp_all, dim3(grid), dim3(320), 0, g.stream, P, n, C);
 }
 
 // one FarnebackUpdateFlow_Blur iteration at level k: matrices from the current flow, box sums, solve
@@ -851,10 +928,7 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
     const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     if (g.prof) ctx->kern_ev_used = 0;
     const int np = n - 1;
-    pyramid_level<3>(ctx, g, d_small, n);
-    pyramid_level<2>(ctx, g, d_small, n);
-    pyramid_level<1>(ctx, g, d_small, n);
-    pyramid_level<0>(ctx, g, d_small, n);
+    pyramid_and_polyexp(ctx, g, d_small, n);
     for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
         const int w = S >> k, h = S >> k;
         const int64_t plane = (int64_t)w * h;
