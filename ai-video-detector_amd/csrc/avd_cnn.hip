@@ -47,7 +47,7 @@ struct ConvGeom {
 // zero-bordered 224 x 224 input image [frame][232][232][4 channels, the fourth zero]; half stage ky holds the 8 x 4 = 32
 // (kx, c) values of kernel row ky (kx = 7 and c = 3 carry zero weights), i.e. chunk j of a row = the two pixels
 // (2 ox + 2 j, 2 ox + 2 j + 1) of image row 2 oy + ky in border coordinates: 16 contiguous, 16-byte aligned bytes.
-template <int BM, int WAVES_M, int TI, int MODE>
+template <int BM, int WAVES_M, int TI, int MODE, int KS>
 __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                   const float* __restrict__ bias, const uint16_t* __restrict__ R,
                                                   uint16_t* __restrict__ Y, ConvGeom g, int relu)
@@ -71,22 +71,30 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
     // ---- the activation rows this lane gathers per half stage (instruction q: tile row wave * RA + q * 16 + lane / 4)
-    int gy[QA], gx[QA], gb[QA], cw[QA];
-    bool gv[QA];
+    // MODE 0 keeps per row: the pixel index of tap (0, 0) (rin0), a 9-bit mask of the taps that fall inside the image, and
+    // the chunk that belongs in this lane's LDS slot; a tap then costs one scalar offset and a dozen vector operations
+    int rin0[QA], cw[QA];
+    unsigned tapmask[QA];
     const int hw = g.hout * g.wout;
 #pragma unroll
     for (int q = 0; q < QA; q++) {
         const int r = wave * RA + q * 16 + (lane >> 2), m = m0 + r;
-        gv[q] = m < g.m_out;
+        const bool valid = m < g.m_out;
         const int img = m / hw, rem = m - img * hw, oy = rem / g.wout, ox = rem - oy * g.wout;
         cw[q] = (lane & 3) ^ swz((r >> 2) & 3);             // the chunk that belongs in this lane's LDS slot
         if (MODE == 1) {                                     // byte offset of pixel (2 oy, 2 ox + 2 chunk) of the bordered image
-            gb[q] = gv[q] ? ((img * kImgSide + 2 * oy) * kImgSide + 2 * ox + 2 * cw[q]) * 8 : 0;
-            gy[q] = gx[q] = 0;
+            rin0[q] = valid ? ((img * kImgSide + 2 * oy) * kImgSide + 2 * ox + 2 * cw[q]) * 8 : 0;
+            tapmask[q] = 0;
         } else {
-            gy[q] = oy * g.stride - g.pad;
-            gx[q] = ox * g.stride - g.pad;
-            gb[q] = img * g.hin * g.win;
+            const int y0 = oy * g.stride - g.pad, x0 = ox * g.stride - g.pad;
+            rin0[q] = (img * g.hin + y0) * g.win + x0;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < KS * KS; t++) {
+                const int yi = y0 + t / KS, xi = x0 + t % KS;
+                if (valid && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win) mk |= 1u << t;
+            }
+            tapmask[q] = mk;
         }
     }
     unsigned vob[QB];
@@ -103,11 +111,10 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
         for (int q = 0; q < QA; q++) {
             unsigned off;
             if (MODE == 1) {
-                off = (unsigned)(gb[q] + hs * (kImgSide * 8));    // kernel row ky = hs: one image row down
+                off = (unsigned)(rin0[q] + hs * (kImgSide * 8));  // kernel row ky = hs: one image row down
             } else {
-                const int yi = gy[q] + is_dy, xi = gx[q] + is_dx;
-                const bool ok = gv[q] && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win;
-                const int rin = gb[q] + yi * g.win + xi;
+                const int rin = rin0[q] + is_dy * g.win + is_dx;  // (the tap offset is uniform: scalar arithmetic)
+                const bool ok = (tapmask[q] >> (is_dy * KS + is_dx)) & 1u;
                 off = (unsigned)(kZeroPage * 2) + (unsigned)((rin >> 4) * g.cpb + is_cb) * 1024u + (unsigned)((rin & 15) * 64) +
                       (unsigned)((cw[q] ^ swz((rin >> 2) & 3)) << 4);
                 off = ok ? off : (unsigned)(lane * 16);       // outside the image (or past the last pixel): the zero page
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
         }
         if (++is_cb == g.cpb) {
             is_cb = 0;
-            if (++is_dx == g.ksize) { is_dx = 0; ++is_dy; }
+            if (++is_dx == KS) { is_dx = 0; ++is_dy; }
         }
     };
 
@@ -367,7 +374,7 @@ int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float*
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
-    if (stem) return go(k_conv_bf16<256, 8, 2, 1>, 256, 64);
+    if (stem) return go(k_conv_bf16<256, 8, 2, 1, 1>, 256, 64);
     // 256-pixel tiles for the long-K layers that fill the chip.  128 x 128 tiles (74 registers, 16 KiB per ring slot: several
     // workgroups per CU) where 256-pixel tiles would leave most of the chip idle (the 14 x 14 and 7 x 7 stages), and for the
     // short-K 1x1 layers, which move bytes rather than multiply: there the time goes to load / store latency, and
@@ -376,11 +383,21 @@ int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float*
     const int bn_big = cout % 256 == 0 ? 256 : cout % 128 == 0 ? 128 : 64;
     const int wgs_big = ((g.m_out + 255) / 256) * (cout / bn_big);
     const bool small_ok = cout % 128 == 0;
-    const bool want_small = wgs_big < ctx->num_cus * 3 / 2 || g.nh <= 8;
-    if (small_ok && force != 1 && (want_small || force == 2)) return go(k_conv_bf16<128, 4, 2, 0>, 128, 128);
-    if (bn_big == 256) return go(k_conv_bf16<256, 2, 8, 0>, 256, 256);
-    if (bn_big == 128) return go(k_conv_bf16<256, 4, 4, 0>, 256, 128);
-    return go(k_conv_bf16<256, 8, 2, 0>, 256, 64);
+    // tuning knobs (A/B only): AVD_CNN_FILL = workgroups of the 256-pixel tiling, in percent of the CU count, below which the
+    // 128 x 128 tiling is taken; AVD_CNN_SHORTK = largest number of half stages that counts as "short K"
+    static const int fill_pct = [] { const char* e = std::getenv("AVD_CNN_FILL"); return e ? std::atoi(e) : 150; }();
+    static const int short_k = [] { const char* e = std::getenv("AVD_CNN_SHORTK"); return e ? std::atoi(e) : 8; }();
+    const bool want_small = wgs_big * 100 < ctx->num_cus * fill_pct || g.nh <= short_k;
+    if (ksize == 3) {
+        if (small_ok && force != 1 && (want_small || force == 2)) return go(k_conv_bf16<128, 4, 2, 0, 3>, 128, 128);
+        if (bn_big == 256) return go(k_conv_bf16<256, 2, 8, 0, 3>, 256, 256);
+        if (bn_big == 128) return go(k_conv_bf16<256, 4, 4, 0, 3>, 256, 128);
+        return go(k_conv_bf16<256, 8, 2, 0, 3>, 256, 64);
+    }
+    if (small_ok && force != 1 && (want_small || force == 2)) return go(k_conv_bf16<128, 4, 2, 0, 1>, 128, 128);
+    if (bn_big == 256) return go(k_conv_bf16<256, 2, 8, 0, 1>, 256, 256);
+    if (bn_big == 128) return go(k_conv_bf16<256, 4, 4, 0, 1>, 256, 128);
+    return go(k_conv_bf16<256, 8, 2, 0, 1>, 256, 64);
 }
 
 size_t act_elems(size_t rows, int c) { return kZeroPage + (rows + 255) / 256 * 256 * (size_t)c; }

@@ -25,7 +25,7 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_a
 // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...): with lane = (chunk << 4) | row a group reads rows {0-3, 12-15} of
 // one chunk and rows {4-11} of the next, and swz = {0, 2, 3, 1} is what makes those sixteen accesses hit sixteen
 // different 16-byte bank groups (the plain XOR with (r >> 2) & 3 is two-way conflicted for these groups).
-__host__ __device__ __forceinline__ int swz(int k) { return k ? (k % 3) + 1 : 0; }
+__host__ __device__ __forceinline__ int swz(int k) { return (0x78 >> (2 * k)) & 3; }      // {0, 2, 3, 1}
 
 // OPERAND LAYOUT IN HBM ("blocked"): a K-contiguous matrix [rows][K] is stored as 1-KiB blocks of 16 rows x 32 k, block
 // (row / 16, k / 32) at ((row / 16) * (K / 32) + k / 32) * 1 KiB, and INSIDE a block exactly the bytes of the LDS image
