@@ -187,7 +187,11 @@ __global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const Fb
         float t0 = img[y * w + x] * g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int q = 1; q <= 5; q++) {
+#if defined(AVD_POLY_ABL) && (AVD_POLY_ABL & 1)      // timing experiment: one load per pixel instead of eleven
+            const float a = t0 * (float)q, bb = t0 - (float)q;
+#else
             const float a = img[max(y - q, 0) * w + x], bb = img[min(y + q, h - 1) * w + x];
+#endif
             const float p = a + bb;
             t0 = t0 + g[q] * p;
             t1 = t1 + xg[q] * (bb - a);
@@ -201,17 +205,22 @@ __global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const Fb
     }
     __syncthreads();
     const float* r0 = r0s + x + 5; const float* r1 = r1s + x + 5; const float* r2 = r2s + x + 5;
-    double b1 = (double)(r0[0] * g[0]), b2 = 0, b3 = (double)(r1[0] * g[0]), b4 = 0,
-           b5 = (double)(r2[0] * g[0]), b6 = 0;
+#if defined(AVD_POLY_ABL) && (AVD_POLY_ABL & 2)      // timing experiment: float accumulators (results differ)
+    typedef float acc_t;
+#else
+    typedef double acc_t;
+#endif
+    acc_t b1 = (acc_t)(r0[0] * g[0]), b2 = 0, b3 = (acc_t)(r1[0] * g[0]), b4 = 0,
+           b5 = (acc_t)(r2[0] * g[0]), b6 = 0;
 #pragma unroll
     for (int q = 1; q <= 5; q++) {
-        const double tg = (double)(r0[q] + r0[-q]);
-        b1 += tg * (double)g[q];
-        b4 += tg * (double)xxg[q];
-        b2 += (double)((r0[q] - r0[-q]) * xg[q]);
-        b3 += (double)((r1[q] + r1[-q]) * g[q]);
-        b6 += (double)((r1[q] - r1[-q]) * xg[q]);
-        b5 += (double)((r2[q] + r2[-q]) * g[q]);
+        const acc_t tg = (acc_t)(r0[q] + r0[-q]);
+        b1 += tg * (acc_t)g[q];
+        b4 += tg * (acc_t)xxg[q];
+        b2 += (acc_t)((r0[q] - r0[-q]) * xg[q]);
+        b3 += (acc_t)((r1[q] + r1[-q]) * g[q]);
+        b6 += (acc_t)((r1[q] - r1[-q]) * xg[q]);
+        b5 += (acc_t)((r2[q] + r2[-q]) * g[q]);
     }
     float* o = outb + tid * 5;                           // (sub-row, x) order = memory order of the workgroup's rows
     o[0] = (float)(b3 * C->ig11);

@@ -450,6 +450,17 @@ def main():
             "result_check": {"ai_timeline_head": [round(v, 6) for v in result["timeline"][:3]],
                              "dup_density": result["summary"]["dup_density"], **fused["result"]},
         }
+        # the whole step against the HBM roofline: PMC traffic of one clip (every kernel of the path) over the time the GPU
+        # spends per clip at the bench's throughput -- the figure the per-kernel fractions cannot show (the level kernels
+        # hold 119 of 256 CUs and leave the bandwidth to the other clips' kernels)
+        whole = load_pmc().get("whole_clip", {}).get("hbm_bytes") if (n, h, w) == (120, 1080, 1920) else None
+        if whole is not None and world == 1:
+            gbs = whole / (ms_per_step * 1e-3) / 1e9
+            out["roofline_whole_step"] = {
+                "what": "all kernels of one clip (preprocess, hash, pyramid, polynomial expansion, 4 level kernels, flow_up, statistics)",
+                "bound": "hbm", "traffic": whole, "algorithmic_bytes_input_only": preprocess_bytes_per_frame(h, w) * n,
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "note": "PMC HBM traffic per clip (profiles/r02_pmc.json) / ms_per_step with clips in flight"}
         if pcie_fps is not None:
             out["pcie_inclusive_fps"] = round(pcie_fps_inflight if pcie_fps_inflight is not None else pcie_fps, 1)
             out["pcie_inclusive_fps_one_clip_at_a_time"] = round(pcie_fps, 1)
