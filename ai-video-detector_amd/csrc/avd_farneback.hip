@@ -79,6 +79,22 @@ __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* 
     }
     __syncthreads();
     const float* kx = C->gk[K];
+    if (KS == 3) {
+        // every column is filtered at these scales (x = j): a lane does four of them from three aligned words
+        static_assert(KS != 3 || NC == S, "the 3-tap scales filter whole rows");
+        for (int it = tid; it < SROWS * (S / 4); it += 256) {
+            const int r = it / (S / 4), x0 = (it - r * (S / 4)) * 4;
+            const unsigned* wp = reinterpret_cast<const unsigned*>(src[r] + PADX + x0);
+            const unsigned pw = wp[-1], cwd = wp[0], nw = wp[1];
+            const float b[6] = {(float)(pw >> 24), (float)(cwd & 0xFFu), (float)((cwd >> 8) & 0xFFu), (float)((cwd >> 16) & 0xFFu),
+                                (float)(cwd >> 24), (float)(nw & 0xFFu)};
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = __builtin_fmaf(b[e + 1], kx[1], (b[e] + b[e + 2]) * kx[0]);
+            *reinterpret_cast<f4*>(&rowf[r][x0]) = o;
+        }
+    } else
     for (int it = tid; it < SROWS * NC; it += 256) {
         const int r = it / NC, j = it - r * NC;
         const int x = K == 0 ? j : ((j >> 1) << K) + OFF + (j & 1);

@@ -620,7 +620,13 @@ __global__ __launch_bounds__(1024) void k_hash(const float* __restrict__ rowbuf,
     int cell;
     if (P.area_fast) {
         int acc = 0;
-        for (int k = 0; k < cnt; k++) acc += __float_as_int(rb[(int64_t)(y0 + k) * AVD_HASH]);
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = __float_as_int(rb[(int64_t)(y0 + min(k0 + j, cnt - 1)) * AVD_HASH]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += k0 + j < cnt ? v[j] : 0;
+        }
         if (dx < P.fast_simd_w) cell = (acc + 2) >> 2;
         else {
             const float scale = 1.f / (float)P.fast_area;
@@ -629,10 +635,21 @@ __global__ __launch_bounds__(1024) void k_hash(const float* __restrict__ rowbuf,
     } else {
         const float wf = P.ay_first[dy], wm = P.ay_mid[dy], wl = P.ay_last[dy];
         float acc = 0.f;
-        for (int k = 0; k < cnt; k++) {
-            const float beta = k == 0 ? wf : (k == cnt - 1 ? wl : wm);
-            const float t = __fmul_rn(beta, rb[(int64_t)(y0 + k) * AVD_HASH]);
-            acc = k == 0 ? t : __fadd_rn(acc, t);
+        // the sum is a dependent chain in cv2's row order; the LOADS are not: eight rows are fetched at a time (one frame =
+        // one workgroup, so the kernel's time is this chain's memory latency: 35 round trips before, 5 now)
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = rb[(int64_t)(y0 + min(k0 + j, cnt - 1)) * AVD_HASH];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = k0 + j;
+                if (k < cnt) {
+                    const float beta = k == 0 ? wf : (k == cnt - 1 ? wl : wm);
+                    const float t = __fmul_rn(beta, v[j]);
+                    acc = k == 0 ? t : __fadd_rn(acc, t);
+                }
+            }
         }
         cell = (int)rintf(acc);             // saturate_cast<uchar>: round-half-even, clamp
     }
