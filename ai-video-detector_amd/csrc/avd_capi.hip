@@ -616,27 +616,35 @@ static int impl_cnn_forward(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, in
 {
     if (!ctx) return AVD_ERR_ARG;
     if ((!bgr || !logits) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
-    if (n < 0 || n > 256 || h < 2 || w < 2 || row_stride < (int64_t)w * 3) { ctx->err = "bad frame geometry (at most 256 frames per call)"; return AVD_ERR_ARG; }
+    if (n < 0 || h < 2 || w < 2 || row_stride < (int64_t)w * 3) { ctx->err = "bad frame geometry"; return AVD_ERR_ARG; }
     if (n == 0) return AVD_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Workspace& ws = ctx->ws;
     if (!ws.d_cnn_w) { ctx->err = "avd_cnn_set_weights has not been called"; return AVD_ERR_ARG; }
-    if (int e = cnn_reserve(ctx, n)) return e;
+    constexpr int kChunk = 128;                        // frames per forward pass: bounds the activation scratch (4 x 206 MB)
+    if (int e = cnn_reserve(ctx, std::min(n, kChunk))) return e;
     const uint8_t* d_bgr = nullptr;
     const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
     if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
-    if (int e = launch_cnn_forward(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
-    if (reps > 0 && forward_ms) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        for (int r = 0; r < reps; r++)
-            if (int e = launch_cnn_forward(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-        float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        *forward_ms = ms / reps;
+    float total_ms = 0.f;
+    for (int f0 = 0; f0 < n; f0 += kChunk) {
+        const int m = std::min(kChunk, n - f0);
+        const uint8_t* src = d_bgr + (size_t)frame_stride * f0;
+        if (int e = launch_cnn_forward(ctx, src, m, h, w, row_stride, frame_stride)) return e;
+        if (reps > 0 && forward_ms) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            for (int r = 0; r < reps; r++)
+                if (int e = launch_cnn_forward(ctx, src, m, h, w, row_stride, frame_stride)) return e;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            total_ms += ms / reps;
+        }
+        // the logits buffer is reused by the next chunk: the copy is ordered before it on the same stream
+        HIP_TRY(ctx, hipMemcpyAsync(logits + (size_t)f0 * 1000, ws.d_cnn_logits, sizeof(float) * (size_t)m * 1000, hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(logits, ws.d_cnn_logits, sizeof(float) * (size_t)n * 1000, hipMemcpyDeviceToHost, ctx->stream));
+    if (reps > 0 && forward_ms) *forward_ms = total_ms;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return AVD_OK;
 }

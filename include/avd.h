@@ -148,7 +148,7 @@ int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h,
  * bf16 bits, convolutions in forward order (stem; per block conv1 1x1, conv2 3x3, conv3 1x1, then the projection shortcut
  * where there is one), each [cout][kh][kw][cin], then the linear layer [1000][2048]; biases f32 in the same order.
  * avd_cnn_forward: each BGR frame is resized to 224x224 and normalised as in avd_vit_patch_embed; logits: host float
- * [n][1000].  If timing_reps > 0 and forward_ms != NULL the whole forward pass (input conversion to logits, 57 launches)
+ * [n][1000]; any n (more than 128 frames are processed in passes of 128).  If timing_reps > 0 and forward_ms != NULL the whole forward pass (input conversion to logits, 57 launches)
  * is run timing_reps more times between two HIP events and its mean duration is returned (bench hook).
  * avd_cnn_conv: ONE convolution layer on host tensors (test entry): x NHWC bf16 [n][hin][win][cin], w [cout][k][k][cin],
  * bias f32[cout], optional residual NHWC [n][hout][wout][cout] added before the optional ReLU, y NHWC bf16; pad = k / 2;

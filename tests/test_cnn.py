@@ -188,6 +188,19 @@ def test_forward_against_float32(ctx):
 
 
 @pytest.mark.gpu
+def test_forward_in_passes_of_128_frames(ctx):
+    """More frames than one pass holds: the second pass reuses every scratch buffer; frames repeat, so must the logits."""
+    weights, biases = seeded_parameters(0)
+    ctx.cnn_set_weights(weights, biases)
+    base = synth.random_frames(3, 96, 128, seed=9)
+    frames = np.concatenate([base] * 44)[:131]                       # 131 frames: 128 + 3
+    logits, _ = ctx.cnn_forward(frames)
+    assert logits.shape == (131, 1000)
+    for i in range(131):
+        assert np.array_equal(logits[i], logits[i % 3])
+
+
+@pytest.mark.gpu
 def test_forward_needs_weights_and_checks_counts():
     c = _lib.Context(0)
     with pytest.raises(_lib.AvdError):
