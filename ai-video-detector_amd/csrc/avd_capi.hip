@@ -596,6 +596,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
 {
     if (!ctx || !name) return AVD_ERR_ARG;
     if (std::strcmp(name, "fb_fused") == 0) { ctx->fb_fused = value & 0xF; return AVD_OK; }
+    if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
     ctx->err = std::string("unknown option: ") + name;
     return AVD_ERR_ARG;
 }

@@ -379,7 +379,8 @@ int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float*
     // workgroups per CU) where 256-pixel tiles would leave most of the chip idle (the 14 x 14 and 7 x 7 stages), and for the
     // short-K 1x1 layers, which move bytes rather than multiply: there the time goes to load / store latency, and
     // co-resident workgroups are what hides it.
-    static const int force = [] { const char* e = std::getenv("AVD_CNN_TILES"); return e ? std::atoi(e) : 0; }();   // 1: always 256, 2: always 128 x 128
+    static const int env_force = [] { const char* e = std::getenv("AVD_CNN_TILES"); return e ? std::atoi(e) : 0; }();
+    const int force = ctx->cnn_tiles ? ctx->cnn_tiles : env_force;   // avd_set_option "cnn_tiles" / AVD_CNN_TILES: 1 = always 256-pixel tiles, 2 = 128 x 128 wherever possible
     const int bn_big = cout % 256 == 0 ? 256 : cout % 128 == 0 ? 128 : 64;
     const int wgs_big = ((g.m_out + 255) / 256) * (cout / bn_big);
     const bool small_ok = cout % 128 == 0;

@@ -148,6 +148,7 @@ struct avd_ctx {
     void* comm = nullptr;            // RCCL communicator (avd_comm.cpp), bound at run time
     int comm_rank = 0, comm_world = 1;
     void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
+    int cnn_tiles = 0;              // convolution tiling of the CNN extension: 0 = heuristic, 1 = 256-pixel tiles, 2 = 128 x 128 wherever possible
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
 };
 

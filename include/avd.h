@@ -217,7 +217,9 @@ int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
 int avd_set_profiling(avd_ctx* ctx, int enable);
 /* Tuning / test switches (no effect on results).  "fb_fused": bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
  * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
- * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM. */
+ * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM.  "cnn_tiles": tiling of the
+ * CNN extension's convolutions, 0 = by layer shape (default), 1 = 256-pixel tiles everywhere, 2 = 128 x 128 tiles wherever the
+ * channel count allows (the accumulation order of an output does not depend on the tiling: results are bit-identical). */
 int avd_set_option(avd_ctx* ctx, const char* name, int value);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 

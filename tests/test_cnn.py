@@ -188,6 +188,28 @@ def test_forward_against_float32(ctx):
 
 
 @pytest.mark.gpu
+def test_every_tiling_gives_the_same_bits(ctx):
+    """The 256 x 256 / 256 x 128 / 256 x 64 / 128 x 128 bodies accumulate an output's K terms in the same order."""
+    outs = {}
+    try:
+        for policy in (0, 1, 2):
+            ctx.set_option("cnn_tiles", policy)
+            res = []
+            for (n, h, w, cin, cout, k, stride) in [(2, 24, 24, 64, 256, 1, 1), (1, 40, 40, 128, 128, 3, 1), (1, 33, 31, 256, 512, 3, 2),
+                                                    (1, 48, 48, 64, 64, 3, 1)]:
+                r = np.random.default_rng(n * 1000 + cout + k)
+                x = r.standard_normal((n, h, w, cin)).astype(np.float32)
+                wt = (r.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+                b = (r.standard_normal(cout) * 0.1).astype(np.float32)
+                res.append(ctx.cnn_conv(x, wt, b, stride=stride, relu=True))
+            outs[policy] = res
+    finally:
+        ctx.set_option("cnn_tiles", 0)
+    for a, b1, b2 in zip(outs[0], outs[1], outs[2]):
+        assert np.array_equal(a, b1) and np.array_equal(a, b2)
+
+
+@pytest.mark.gpu
 def test_forward_in_passes_of_128_frames(ctx):
     """More frames than one pass holds: the second pass reuses every scratch buffer; frames repeat, so must the logits."""
     weights, biases = seeded_parameters(0)
