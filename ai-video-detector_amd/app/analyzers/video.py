@@ -41,14 +41,18 @@ def analyze(path: str, meta: dict):
 
         seen = {}
 
+        nv12 = getattr(src, "surface", "bgr") == "nv12"      # decoder pictures: the colour conversion happens on the GPU
+
         def frames():
             for fr in src.sampled(step):
-                seen.setdefault("npix", int(fr.shape[0]) * int(fr.shape[1]))
+                plane = fr[0] if nv12 else fr
+                seen.setdefault("npix", int(plane.shape[0]) * int(plane.shape[1]))
                 yield fr
 
         # one pooled context for the duration of the request (bounded pool: api.py:133 runs this on worker threads)
         with _analyzer.default_pool().borrow(device) as ctx:
-            rec = _analyzer.FrameAnalyzer(chunk=chunk, ctx=ctx).records_stream(frames())
+            fa = _analyzer.FrameAnalyzer(chunk=chunk, ctx=ctx)
+            rec = fa.records_stream_nv12(frames()) if nv12 else fa.records_stream(frames())
     finally:
         src.close()
     return records_to_result(rec, seen.get("npix", 0), w, h, fps, duration)

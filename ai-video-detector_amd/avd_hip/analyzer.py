@@ -154,6 +154,25 @@ class FrameAnalyzer:
         rec = self.ctx.analyze_frames(stack)
         return rec[1:] if carry is not None else rec
 
+    # -- the same for decoder surfaces: an iterable of (y uint8[H,W], uv uint8[H/2,W]) pairs ----------------
+    def records_stream_nv12(self, surfaces) -> np.ndarray:
+        out = []
+        buf = []
+        carry = None
+        for sf in surfaces:
+            buf.append(sf)
+            if len(buf) >= self.chunk:
+                out.append(self._flush_nv12(buf, carry))
+                carry, buf = buf[-1], []
+        if buf:
+            out.append(self._flush_nv12(buf, carry))
+        return np.concatenate(out) if out else np.zeros(0, _lib.RECORD_DTYPE)
+
+    def _flush_nv12(self, buf, carry):
+        items = ([carry] if carry is not None else []) + buf
+        rec = self.ctx.analyze_frames_nv12(np.stack([y for y, _ in items]), np.stack([uv for _, uv in items]))
+        return rec[1:] if carry is not None else rec
+
 
 class ClipsInFlight:
     """Throughput mode for a service that analyses many clips on one GPU: up to ``depth`` clips are in

@@ -9,8 +9,11 @@ capture properties the reference falls back to when ffprobe metadata is missing
 (video.py:14-17).  Probed in this order:
 
   1. ``*.npy``  raw decoded stack uint8[T,H,W,3] (memory-mapped) -- used by tests / tools;
-  2. ``cv2.VideoCapture`` if OpenCV is importable (identical decode to the reference);
-  3. ``ffmpeg``/``ffprobe`` CLIs if on PATH (rawvideo bgr24 pipe).
+  2. ``*.y4m``  YUV4MPEG2, 8-bit 4:2:0 (what ``ffmpeg -i in.mp4 out.y4m`` writes, i.e. a decoder's pictures BEFORE the colour
+     conversion): memory-mapped, handed over as NV12 surfaces to ``avd_analyze_frames_nv12`` -- the YUV->BGR step of
+     ``cap.retrieve()`` happens in the HIP kernel (SURVEY.md section 8f, row N1), no BGR frame ever exists;
+  3. ``cv2.VideoCapture`` if OpenCV is importable (identical decode to the reference);
+  4. ``ffmpeg``/``ffprobe`` CLIs if on PATH (rawvideo bgr24 pipe).
 If nothing can open the file the analyzer returns the reference's "capture not opened"
 result (video.py:12-13).
 """
@@ -25,6 +28,7 @@ import numpy as np
 
 
 class FrameSource:
+    surface: str = "bgr"        # what sampled() yields: "bgr" = uint8[H,W,3]; "nv12" = (y uint8[H,W], uv uint8[H/2,W] interleaved U,V)
     fps: float = 0.0
     width: int = 0
     height: int = 0
@@ -48,6 +52,86 @@ class NpySource(FrameSource):
     def sampled(self, step):
         for i in range(0, self.frame_count, step):
             yield np.ascontiguousarray(self._arr[i])
+
+
+class Y4mSource(FrameSource):
+    """YUV4MPEG2 file with 8-bit 4:2:0 pictures (C420, C420jpeg, C420mpeg2, C420paleo -- chroma siting does not enter
+    libswscale's unscaled yuv420p -> bgr24 conversion, which takes the nearest chroma sample).  Frames are read through a
+    memory map; ``sampled`` yields NV12 surfaces (the U and V planes interleaved on the host: 0.5 byte per pixel)."""
+    surface = "nv12"
+
+    def __init__(self, path: str):
+        with open(path, "rb") as f:
+            header = f.readline(4096)
+        if not header.startswith(b"YUV4MPEG2 ") or not header.endswith(b"\n"):
+            raise ValueError("not a YUV4MPEG2 stream")
+        self._data_off = len(header)
+        w = h = 0
+        num, den, chroma = 0, 1, "420"
+        for tok in header.split()[1:]:
+            tag, val = tok[:1], tok[1:].decode("ascii", "replace")
+            if tag == b"W":
+                w = int(val)
+            elif tag == b"H":
+                h = int(val)
+            elif tag == b"F":
+                a, _, b = val.partition(":")
+                num, den = int(a), int(b or 1)
+            elif tag == b"C":
+                chroma = val
+        if w <= 0 or h <= 0 or (w | h) & 1:
+            raise ValueError("bad or odd picture size")
+        if not chroma.startswith("420") or "p1" in chroma:          # 420p10 / p12 / p16: more than 8 bits
+            raise ValueError("only 8-bit 4:2:0 is supported")
+        self.width, self.height = w, h
+        self.fps = num / den if den else 0.0
+        self._luma, self._chroma = w * h, (w // 2) * (h // 2)
+        self._frame_bytes = self._luma + 2 * self._chroma
+        self._map = np.memmap(path, dtype=np.uint8, mode="r")
+        # every picture is preceded by "FRAME" [parameters] "\n"; the marker length is constant in files written by ffmpeg,
+        # but it is read per frame anyway
+        self._offsets = []
+        pos = self._data_off
+        size = self._map.shape[0]
+        while pos + 6 <= size:
+            end = pos
+            limit = min(size, pos + 256)
+            while end < limit and self._map[end] != 0x0A:
+                end += 1
+            if end >= limit or bytes(self._map[pos:pos + 5]) != b"FRAME":
+                break
+            if end + 1 + self._frame_bytes > size:
+                break
+            self._offsets.append(end + 1)
+            pos = end + 1 + self._frame_bytes
+        self.frame_count = len(self._offsets)
+
+    def sampled(self, step):
+        h, w = self.height, self.width
+        for i in range(0, self.frame_count, step):
+            o = self._offsets[i]
+            y = np.asarray(self._map[o:o + self._luma]).reshape(h, w)
+            u = self._map[o + self._luma:o + self._luma + self._chroma].reshape(h // 2, w // 2)
+            v = self._map[o + self._luma + self._chroma:o + self._frame_bytes].reshape(h // 2, w // 2)
+            uv = np.empty((h // 2, w), np.uint8)
+            uv[:, 0::2] = u
+            uv[:, 1::2] = v
+            yield y, uv
+
+    def close(self):
+        self._map = None
+
+
+def write_y4m(path: str, y: np.ndarray, uv: np.ndarray, fps=(30, 1)) -> None:
+    """NV12 surfaces (y uint8[N,H,W], uv uint8[N,H/2,W] interleaved) -> a YUV4MPEG2 file (tests, tools)."""
+    n, h, w = y.shape
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F%d:%d Ip A1:1 C420jpeg\n" % (w, h, fps[0], fps[1]))
+        for i in range(n):
+            f.write(b"FRAME\n")
+            f.write(np.ascontiguousarray(y[i]).tobytes())
+            f.write(np.ascontiguousarray(uv[i][:, 0::2]).tobytes())
+            f.write(np.ascontiguousarray(uv[i][:, 1::2]).tobytes())
 
 
 class Cv2Source(FrameSource):
@@ -115,6 +199,11 @@ def open_source(path: str) -> Optional[FrameSource]:
     if str(path).endswith(".npy"):
         try:
             return NpySource(path)
+        except (OSError, ValueError):
+            return None
+    if str(path).endswith(".y4m"):
+        try:
+            return Y4mSource(path)
         except (OSError, ValueError):
             return None
     try:

@@ -159,3 +159,64 @@ def test_analyze_uses_capture_properties_when_metadata_is_missing(monkeypatch):
     with _module("cv2", mod):
         out = video.analyze("clip.mp4", {"fps": 30.0, "width": 1920, "height": 1080, "duration": 4.4})
     assert (out["summary"]["w"], out["summary"]["fps"]) == (1920, 30.0) and len(out["timeline"]) == 4   # meta wins; step 15
+
+
+# ---- YUV4MPEG2: decoder pictures before the colour conversion (rows A1 + N1 together, no fakes) --------------------
+def _write_y4m_clip(tmp_path, n=7, h=96, w=128, fps=(30, 1), seed=3):
+    from avd_hip import synth
+    clip = synth.make_clip(n, h, w, seed=seed, dup_every=3)
+    y, uv = synth.bgr_to_nv12(clip)
+    path = str(tmp_path / "clip.y4m")
+    sources.write_y4m(path, y, uv, fps=fps)
+    return path, y, uv
+
+
+def test_y4m_source_reads_back_what_was_written(tmp_path):
+    path, y, uv = _write_y4m_clip(tmp_path, n=7, fps=(30000, 1001))
+    src = sources.open_source(path)
+    assert isinstance(src, sources.Y4mSource) and src.surface == "nv12"
+    assert (src.width, src.height, src.frame_count) == (128, 96, 7) and abs(src.fps - 29.97) < 0.01
+    got = list(src.sampled(3))                                         # frames 0, 3, 6
+    assert len(got) == 3
+    for (gy, guv), i in zip(got, (0, 3, 6)):
+        assert np.array_equal(gy, y[i]) and np.array_equal(guv, uv[i])
+    src.close()
+
+
+def test_y4m_rejects_what_it_cannot_read(tmp_path):
+    bad = tmp_path / "bad.y4m"
+    bad.write_bytes(b"RIFF....")
+    assert sources.open_source(str(bad)) is None                       # "capture not opened", not an exception
+    deep = tmp_path / "deep.y4m"
+    deep.write_bytes(b"YUV4MPEG2 W64 H64 F25:1 C420p10\n")
+    assert sources.open_source(str(deep)) is None
+    odd = tmp_path / "odd.y4m"
+    odd.write_bytes(b"YUV4MPEG2 W63 H64 F25:1 C420\n")
+    assert sources.open_source(str(odd)) is None
+    cut = tmp_path / "cut.y4m"                                          # a truncated last picture is dropped
+    path, y, uv = _write_y4m_clip(tmp_path, n=3)
+    data = open(path, "rb").read()
+    cut.write_bytes(data[:-100])
+    src = sources.open_source(str(cut))
+    assert src.frame_count == 2
+
+
+@pytest.mark.gpu
+def test_analyze_a_y4m_file_end_to_end(tmp_path, oracle, monkeypatch):
+    """video.analyze on a .y4m: the NV12 ingest kernel does the colour conversion; the result equals the oracle's chain
+    swscale-style NV12 -> BGR, then video.py on the sampled frames -- across a streaming chunk boundary with its halo."""
+    from avd_hip import synth
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ai-video-detector_amd"))
+    from app.analyzers import video
+    n, h, w = 40, 96, 128
+    clip = synth.make_clip(n, h, w, seed=21, dup_every=4)
+    y, uv = synth.bgr_to_nv12(clip)
+    path = str(tmp_path / "clip.y4m")
+    sources.write_y4m(path, y, uv, fps=(8, 1))                          # 8 fps: step = round(8 / 2) = 4 -> frames 0, 4, .., 36
+    monkeypatch.setenv("AVD_CHUNK_FRAMES", "4")                        # 10 sampled frames in chunks of 4 + halo
+    meta = {"width": 0, "height": 0, "fps": 0.0, "duration": 0.0}      # ffprobe missing: the source's properties are used
+    got = video.analyze(path, meta)
+    sampled = oracle.nv12_to_bgr(y[::4], uv[::4])
+    want = oracle.analyze_sampled_frames(sampled, {"fps": 8.0, "width": w, "height": h, "duration": n / 8.0})
+    assert got["timeline"] == want["timeline"] and got["timeline"] is got["timeline_ai"]
+    assert got["summary"] == want["summary"]
