@@ -680,7 +680,7 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     Workspace& ws = ctx->ws;
     if (!ws.d_vit_w) { ctx->err = "avd_vit_set_weights has not been called"; return AVD_ERR_ARG; }
     const size_t m = (size_t)n * 196;
-    const size_t m_pad = (m + kGemmRowPad - 1) / kGemmRowPad * kGemmRowPad;   // the persistent GEMM reads whole tiles of A (256 or 384 rows)
+    const size_t m_pad = (m + kGemmRowPad - 1) / kGemmRowPad * kGemmRowPad;   // the persistent GEMM reads whole 256-row tiles of A
     if (ws.vit_patch_elems < m_pad * 768) {
         if (int e = dev_alloc(ctx, ws.d_vit_patches, m_pad * 768)) return e;
         HIP_TRY(ctx, hipMemsetAsync(ws.d_vit_patches, 0, m_pad * 768 * sizeof(uint16_t), ctx->stream));

@@ -181,7 +181,7 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
 int launch_vit_patch_embed(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int64_t row_stride, int64_t frame_stride,
                            const uint16_t* d_wt, const float* d_bias, void* d_tokens, int tokens_bf16, uint16_t* d_patches);
 void gemm_block_operand(const uint16_t* src_row_major, uint16_t* dst_blocked, int rows, int K);
-constexpr int kGemmRowPad = 768;     // lcm of the GEMM's tile heights (256, 384): A is allocated in multiples of it
+constexpr int kGemmRowPad = 256;     // the GEMM's tile height: A is allocated in multiples of it
 int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt, const float* d_bias, void* d_c, int out_bf16,
                         int M, int N, int K);
 // avd_cnn.hip (extension): ResNet-50-style forward as implicit GEMMs on the matrix cores

@@ -19,7 +19,7 @@
 // instruction touched sixteen half lines (64 bytes of each of 16 rows) and the L2 -> LDS path, not the matrix pipe, set
 // the kernel's time (profiles/r02_experiments.md).
 //
-// The GEMM: a 512-thread workgroup per CU walks 256 x 256 (or 384 x 192) output tiles; 8 waves, a wave owns 8 x 4 (6 x 6)
+// The GEMM: a 512-thread workgroup per CU walks 256 x 256 output tiles; 8 waves, a wave owns 8 x 4
 // MFMA tiles of v_mfma_f32_16x16x32_bf16.  The staging unit is a HALF stage, 32 deep in K (64 B per row, 32 KiB for both
 // operands of a 256 x 256 tile): a ring of four of them in LDS keeps THREE in flight beside the one being read, with
 // counted vmcnt + a raw s_barrier per half stage (a __syncthreads would drain the LDS-DMAs).  A ds_read_b128 of a
@@ -70,9 +70,8 @@ __global__ __launch_bounds__(256) void k_vit_patchify(const uint8_t* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------
 // The GEMM kernel is persistent: one workgroup per CU walks a list of tiles and NEVER drains its pipeline.
-//  * the tile SHAPE is a template parameter, chosen by the launcher so that the tile count fits the CU count: the patch
-//    embedding of a 120-frame clip is 23 520 x 768 outputs -- 276 tiles of 256 x 256 are TWO rounds on 256 CUs with the
-//    second one 8 % full, 248 tiles of 384 x 192 (8 waves as 4 x 2, a wave owns 96 x 96 = 6 x 6 MFMA tiles) are one;
+//  * the tile SHAPE is a template parameter (TileShape); 256 x 256 is the one instantiated -- 384 x 192, one round of
+//    tiles for a 120-frame clip instead of two, needs 144 accumulator registers per wave and spills: slower at every size;
 //  * the half-stage stream is continuous across tiles: during the last steps of a tile the LDS-DMAs of the next tile's
 //    first half stages are already issued -- no prologue latency, no drained ring behind the epilogue;
 //  * the product is formed TRANSPOSED (mfma(b, a): the accumulator tile has n on its rows and m on the lane), so a lane
@@ -346,8 +345,6 @@ int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt,
 {
     if (M <= 0) return 0;
     if (N != kDim || K != kDim) { ctx->err = "gemm_bf16_nt: built for N = K = 768 (the ViT-B/16 patch embedding)"; return AVD_ERR_ARG; }
-    // tile shape: 0 = by cost, 1 = 256 x 256, 3 = 384 x 192
-    static const int variant = [] { const char* e = std::getenv("AVD_GEMM_VARIANT"); return e ? std::atoi(e) : 0; }();
     auto go = [&](auto kern, int grid, size_t lds, auto... args) -> int {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, args...);
@@ -356,27 +353,14 @@ int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt,
     };
     {
         // persistent kernel, one workgroup per CU (LDS: ring + bias), grid a multiple of 8 so that the XCD-aware order is
-        // a bijection.  Tile shape: the one whose tile count wastes fewer CU rounds (cost = rounds x tile area).
-        using Sq = TileShape<2, 8, 4>;                      // 256 x 256
-        using Wd = TileShape<4, 6, 6>;                      // 384 x 192
-        auto plan = [&](int bm, int bn, int& grid) -> int64_t {
-            if (N % bn) return INT64_MAX;
-            const int tiles = ((M + bm - 1) / bm) * (N / bn);
-            grid = ctx->num_cus / 8 * 8;
-            if (grid < 8) grid = 8;
-            if (grid > (tiles + 7) / 8 * 8) grid = (tiles + 7) / 8 * 8;
-            return (int64_t)((tiles + grid - 1) / grid) * bm * bn;
-        };
-        int grid_sq = 0, grid_wd = 0;
-        const int64_t cost_sq = plan(Sq::BM, Sq::BN, grid_sq), cost_wd = plan(Wd::BM, Wd::BN, grid_wd);
-        // the 384 x 192 body needs more registers than a wave has (it spills): taken only when it saves a whole round of tiles
-        const bool wide = variant == 3 ? true : variant == 1 ? false : cost_wd * 3 < cost_sq * 2;
-        if (wide && cost_wd == INT64_MAX) { ctx->err = "gemm_bf16_nt: N must be a multiple of 192 for the 384 x 192 tile"; return AVD_ERR_ARG; }
-        const size_t lds = (size_t)(wide ? Wd::LDS : Sq::LDS) + (size_t)N * sizeof(float);
-        if (wide) {
-            if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Wd>, grid_wd, lds, d_a, d_bt, d_bias, d_c, M, N);
-            return go(k_gemm_bf16_nt_persistent<kDim, 0, Wd>, grid_wd, lds, d_a, d_bt, d_bias, d_c, M, N);
-        }
+        // a bijection.  256 x 256 tiles: a 384 x 192 shape (one round of tiles for a 120-frame clip instead of two) was
+        // measured slower at every size (144 accumulator registers + fragments spill): 0.0478 vs 0.0454 ms at 120 frames.
+        using Sq = TileShape<2, 8, 4>;
+        const int tiles = ((M + Sq::BM - 1) / Sq::BM) * (N / Sq::BN);
+        int grid_sq = ctx->num_cus / 8 * 8;
+        if (grid_sq < 8) grid_sq = 8;
+        if (grid_sq > (tiles + 7) / 8 * 8) grid_sq = (tiles + 7) / 8 * 8;
+        const size_t lds = (size_t)Sq::LDS + (size_t)N * sizeof(float);
 #ifdef AVD_GEMM_DEBUG
         // timing experiments (tools/gemm_dbg.sh): AVD_GEMM_DBG bits 1 = no LDS-DMA, 2 = no MFMA, 4 = no stores, 8 = no fragment reads
         static const int dbg = [] { const char* e = std::getenv("AVD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();
