@@ -64,7 +64,7 @@ def test_patchify_reference_layout():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 360, 640), (5, 1080, 1920), (1, 135, 240)])
+@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 360, 640), (5, 1080, 1920), (1, 135, 240), (1, 2160, 3840)])
 def test_patch_embed_against_numpy(ctx, n, h, w):
     rng = np.random.default_rng(n * 1000 + h)
     frames = synth.random_frames(n, h, w, seed=h) if h != 360 else synth.make_clip(n, h, w, seed=3)
