@@ -8,13 +8,15 @@
 // The scalar tail (percentiles, variances, tts_like, timeline; audio.py:63-110) is O(windows) numpy on the host
 // (avd_hip/audio.py), exactly the reference's calls.
 //
-// The transform: a window is 8000 samples (0.5 s at 16 kHz) = 2^6 * 5^3, a real DFT of 4001 bins.  It is evaluated as a
-// direct DFT in double with EXACT twiddles -- cos(2 pi j / L) tabulated once on the host, the index (k * n) mod L kept
-// incrementally, sin taken from the same table a quarter period away -- one lane per bin, window and table in LDS
-// (2 x 64 KB).  64 M multiply-adds per window; a 60 s clip is 120 windows = 15 GFLOP of f64: well under a millisecond
-// of arithmetic, no FFT plan, no bit reversal, and an error of ~1e-13 relative (far inside the 1e-4 tolerance of the
-// path; pocketfft's own is ~1e-15).  Windows whose length is not a multiple of 4 (only the last one of a stream can
-// be) read sin from a second table in global memory.
+// The transform: a window is 8000 samples (0.5 s at 16 kHz) = 80 x 100, a real DFT of 4001 bins, in double with EXACT
+// twiddles (cos(2 pi j / 8000) tabulated once on the host; the sine is the entry a quarter period away):
+//  * full windows: a hundred 80-point DFTs, a twiddle and eighty 100-point DFTs (k_audio_fft_a / _b), each small DFT a
+//    direct sum whose factors are entries of that one table -- 2.9 M multiply-adds per window, 0.58 ms per 60 s track;
+//  * any other length (the short last window of a stream, or a caller's own window size): the direct 4001 x L sum
+//    (k_audio_dft: one lane per bin, window and table in LDS; 64 M multiply-adds per 8000-sample window, 3.4 ms per track
+//    when every window goes this way).  Windows whose length is not a multiple of 4 read the sine from a second table.
+// Either way the error against numpy's pocketfft is ~1e-13 relative (the order of additions), far inside the 1e-4
+// tolerance of the path.
 #include <cmath>
 #include <vector>
 #include "avd_internal.h"
@@ -63,10 +65,10 @@ __global__ __launch_bounds__(256) void k_audio_prepare(const float* __restrict__
 // grid (windows, ceil(max_bins / 256)); LDS: window [L] + cosine table [L] (dynamic, 16 * L bytes)
 __global__ __launch_bounds__(256) void k_audio_dft(const double* __restrict__ xw, int64_t n, int win,
                                                   const double* __restrict__ cos_full, const double* __restrict__ cos_last,
-                                                  const double* __restrict__ sin_last, double* __restrict__ mag)
+                                                  const double* __restrict__ sin_last, double* __restrict__ mag, int first_window)
 {
     extern __shared__ __align__(16) double lds[];
-    const int wdx = blockIdx.x, tid = threadIdx.x;
+    const int wdx = first_window + blockIdx.x, tid = threadIdx.x;   // the windows before first_window went through the FFT path
     const int64_t base = (int64_t)wdx * win;
     const int L = (int)((n - base) < win ? (n - base) : win);
     const int nb = L / 2 + 1;
@@ -102,6 +104,74 @@ __global__ __launch_bounds__(256) void k_audio_dft(const double* __restrict__ xw
         }
     }
     mag[(int64_t)wdx * (win / 2 + 1) + k] = hypot(re, im) + 1e-9;
+}
+
+// ---- pass 2, fast path: full windows of 8000 samples ---------------------------------------------------------------
+// 8000 = 80 x 100.  With n = 100 n1 + n2 and k = k1 + 80 k2:
+//   X[k1 + 80 k2] = sum_{n2} W_100^(n2 k2) * ( W_8000^(n2 k1) * sum_{n1} x[100 n1 + n2] W_80^(n1 k1) )
+// i.e. a hundred 80-point DFTs, a twiddle, and eighty 100-point DFTs of which only k2 <= 50 is needed (bins 0..4000):
+// 2.9 M real multiply-adds per window instead of 64 M, each of the small DFTs evaluated directly in double with entries of
+// the SAME 8000-entry cosine table the direct form uses (W_80^m = W_8000^(100 m), W_100^m = W_8000^(80 m), sines a quarter
+// period away): no approximation anywhere, the result differs from the direct sum only by the order of additions
+// (~1e-14 relative).  The intermediate B[n2][k1] (16 bytes per entry, 128 KB per window) goes through global memory / L2.
+constexpr int kFftN = 8000, kN1 = 80, kN2 = 100;
+
+__global__ __launch_bounds__(256) void k_audio_fft_a(const double* __restrict__ xw, const double* __restrict__ cos_full,
+                                                    double2* __restrict__ B)
+{
+    extern __shared__ __align__(16) double lds[];          // window [8000] | cosine table [8000]
+    double* x = lds;
+    double* c = lds + kFftN;
+    const int wdx = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < kFftN; i += 256) { x[i] = xw[(int64_t)wdx * kFftN + i]; c[i] = cos_full[i]; }
+    __syncthreads();
+    double2* out = B + (int64_t)wdx * kFftN;
+    for (int o = tid; o < kFftN; o += 256) {
+        const int k1 = o / kN2, n2 = o - k1 * kN2;          // consecutive lanes: consecutive n2, (almost) the same k1
+        double re = 0., im = 0.;
+        int j = 0;                                           // (n1 k1 mod 80) * 100: the index of W_80^(n1 k1) in the table
+        const int stepj = k1 * 100;
+        for (int n1 = 0; n1 < kN1; n1++) {
+            const double v = x[n1 * kN2 + n2];
+            const int js = j >= 2000 ? j - 2000 : j + 6000;  // sin(t) = cos(t - pi / 2)
+            re += v * c[j];
+            im -= v * c[js];
+            j += stepj; if (j >= kFftN) j -= kFftN;
+        }
+        // twiddle W_8000^(n2 k1) = cos - i sin
+        const int t = n2 * k1, ts = t >= 2000 ? t - 2000 : t + 6000;
+        const double tc = c[t], tsn = c[ts];
+        double2 r;
+        r.x = re * tc + im * tsn;
+        r.y = im * tc - re * tsn;
+        out[n2 * kN1 + k1] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_audio_fft_b(const double2* __restrict__ B, const double* __restrict__ cos_full,
+                                                    double* __restrict__ mag)
+{
+    extern __shared__ __align__(16) double lds[];          // cosine table [8000]
+    double* c = lds;
+    const int wdx = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < kFftN; i += 256) c[i] = cos_full[i];
+    __syncthreads();
+    const double2* in = B + (int64_t)wdx * kFftN;
+    for (int k = tid; k <= kFftN / 2; k += 256) {
+        const int k2 = k / kN1, k1 = k - k2 * kN1;          // consecutive lanes: consecutive k1 -> consecutive B entries
+        double re = 0., im = 0.;
+        int j = 0;                                           // (n2 k2 mod 100) * 80
+        const int stepj = k2 * 80;
+        for (int n2 = 0; n2 < kN2; n2++) {
+            const double2 b = in[n2 * kN1 + k1];
+            const int js = j >= 2000 ? j - 2000 : j + 6000;
+            const double wc = c[j], ws = c[js];              // W_100^(n2 k2) = wc - i ws
+            re += b.x * wc + b.y * ws;
+            im += b.y * wc - b.x * ws;
+            j += stepj; if (j >= kFftN) j -= kFftN;
+        }
+        mag[(int64_t)wdx * (kFftN / 2 + 1) + k] = hypot(re, im) + 1e-9;
+    }
 }
 
 // ---- pass 3: spectral sums and the roll-off index ---------------------------------------------------------------
@@ -175,25 +245,38 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope
         ws.audio_win = win; ws.audio_last = last;
     }
-    const size_t xw_need = (size_t)nwin * win, mag_need = (size_t)nwin * (win / 2 + 1);
-    if (ws.audio_buf_elems < xw_need + mag_need) {
+    // full windows of 8000 samples (the reference's half second at 16 kHz) take the two-step FFT path, everything else
+    // (another window length, the short last window of a stream) the direct form
+    static const bool no_fft = [] { const char* e = std::getenv("AVD_AUDIO_DIRECT"); return e && std::atoi(e) != 0; }();   // A/B switch
+    const int nfull = (win == kFftN && !no_fft) ? (last == win ? nwin : nwin - 1) : 0;
+    const size_t xw_need = (size_t)nwin * win, mag_need = (size_t)nwin * (win / 2 + 1), b_need = (size_t)nfull * kFftN * 2;
+    if (ws.audio_buf_elems < xw_need + mag_need + b_need) {
         if (ws.d_audio_buf) (void)hipFree(ws.d_audio_buf);
         ws.d_audio_buf = nullptr;
-        if (hipMalloc((void**)&ws.d_audio_buf, (xw_need + mag_need) * sizeof(double)) != hipSuccess) { ctx->err = "hipMalloc (audio scratch)"; return AVD_ERR_NOMEM; }
-        ws.audio_buf_elems = xw_need + mag_need;
+        if (hipMalloc((void**)&ws.d_audio_buf, (xw_need + mag_need + b_need) * sizeof(double)) != hipSuccess) { ctx->err = "hipMalloc (audio scratch)"; return AVD_ERR_NOMEM; }
+        ws.audio_buf_elems = xw_need + mag_need + b_need;
     }
     double* t = ws.d_audio_tab;
     double *xw = ws.d_audio_buf, *mag = ws.d_audio_buf + xw_need;
+    double2* bbuf = reinterpret_cast<double2*>(ws.d_audio_buf + xw_need + mag_need);
     hipLaunchKernelGGL(k_audio_prepare, dim3(nwin), dim3(256), 0, ctx->stream, d_wav, n, win, (const double*)t,
                        (const double*)(t + 2 * win), xw, d_out);
-    const size_t lds = (size_t)16 * win;
     static bool attr = false;
     if (!attr) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_a, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * kFftN));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_b, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kFftN));
         attr = true;
     }
-    hipLaunchKernelGGL(k_audio_dft, dim3(nwin, (win / 2 + 1 + 255) / 256), dim3(256), lds, ctx->stream, (const double*)xw, n, win,
-                       (const double*)(t + win), (const double*)(t + 2 * win + last), (const double*)(t + 2 * win + 2 * last), mag);
+    if (nfull > 0) {
+        hipLaunchKernelGGL(k_audio_fft_a, dim3(nfull), dim3(256), (size_t)16 * kFftN, ctx->stream, (const double*)xw, (const double*)(t + win), bbuf);
+        hipLaunchKernelGGL(k_audio_fft_b, dim3(nfull), dim3(256), (size_t)8 * kFftN, ctx->stream, (const double2*)bbuf, (const double*)(t + win), mag);
+    }
+    if (nfull < nwin) {
+        const size_t lds = (size_t)16 * win;
+        hipLaunchKernelGGL(k_audio_dft, dim3(nwin - nfull, (win / 2 + 1 + 255) / 256), dim3(256), lds, ctx->stream, (const double*)xw, n, win,
+                           (const double*)(t + win), (const double*)(t + 2 * win + last), (const double*)(t + 2 * win + 2 * last), mag, nfull);
+    }
     hipLaunchKernelGGL(k_audio_reduce, dim3(nwin), dim3(256), 0, ctx->stream, (const double*)mag, win, d_out);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

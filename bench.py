@@ -512,10 +512,10 @@ def main():
                 "timed": "5 whole forward passes (BGR frames in HBM to logits) between two HIP events on the library's stream"}
         if audio is not None:
             out["audio_analyzer"] = {
-                "what": "avd_audio_features: RMS / zero crossings / Hann + direct 8000-point real DFT in double / flatness, roll-off, centroid "
+                "what": "avd_audio_features: RMS / zero crossings / Hann + 8000-point real DFT in double (80 x 100 two-step, exact twiddle table) / flatness, roll-off, centroid "
                         "sums for every half-second window of a 60 s 16 kHz sound track in one call (reference audio.py:40-61), reported apart",
                 "windows": audio["windows"], "gpu_call_ms": round(audio["features_ms"], 3), "host_tail_ms": round(audio["tail_ms"], 3),
-                "windows_per_s": round(audio["windows"] / (audio["features_ms"] * 1e-3), 1), "f64_gflop_per_call": round(audio["windows"] * 4001 * 8000 * 4 / 1e9, 2)}
+                "windows_per_s": round(audio["windows"] / (audio["features_ms"] * 1e-3), 1), "f64_gflop_per_call_direct_form": round(audio["windows"] * 4001 * 8000 * 4 / 1e9, 2)}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(clip, meta, min(args.cpu_frames, n), max(1, min(args.cpu_procs, os.cpu_count() or 1)))
         else:
