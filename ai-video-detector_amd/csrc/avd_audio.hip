@@ -261,13 +261,10 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
     double2* bbuf = reinterpret_cast<double2*>(ws.d_audio_buf + xw_need + mag_need);
     hipLaunchKernelGGL(k_audio_prepare, dim3(nwin), dim3(256), 0, ctx->stream, d_wav, n, win, (const double*)t,
                        (const double*)(t + 2 * win), xw, d_out);
-    static bool attr = false;
-    if (!attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_a, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * kFftN));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_b, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kFftN));
-        attr = true;
-    }
+    // per call (a function attribute belongs to the current device; a process may hold contexts on several)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_a, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * kFftN));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_b, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kFftN));
     if (nfull > 0) {
         hipLaunchKernelGGL(k_audio_fft_a, dim3(nfull), dim3(256), (size_t)16 * kFftN, ctx->stream, (const double*)xw, (const double*)(t + win), bbuf);
         hipLaunchKernelGGL(k_audio_fft_b, dim3(nfull), dim3(256), (size_t)8 * kFftN, ctx->stream, (const double2*)bbuf, (const double*)(t + win), mag);
