@@ -958,7 +958,8 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         const int w = S >> k, h = S >> k;
         const int64_t plane = (int64_t)w * h;
         if (k == AVD_FB_LEVELS - 1) {
-            HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
+            // the coarsest level starts from zero flow: the fused kernel is told so, the two-kernel path reads a cleared buffer
+            if (!((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
         } else {
             const int items = np * 2 * h * (w / 4);
             const float* prev = g.flow[k + 1];
@@ -970,7 +971,7 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         // D never leaves the chip); clear = the two-kernel path below
         if ((ctx->fb_fused >> k) & 1) {
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            if (int e = launch_fb_level(ctx, stream, w, g.poly[k], g.flow[k], np, 3)) return e;
+            if (int e = launch_fb_level(ctx, stream, w, g.poly[k], g.flow[k], np, 3, k == AVD_FB_LEVELS - 1)) return e;
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
             continue;
         }

@@ -130,10 +130,12 @@ __device__ __forceinline__ float border_factor(int p, int len)
     return (p < 5 ? lo : 1.f) * (p >= len - 5 ? hi : 1.f);
 }
 
+// zf (wave-uniform): the flow is known to be zero (first iteration of the coarsest level): whatever the flow buffer holds is
+// ignored, which saves clearing it
 __device__ __forceinline__ void ne_gather2(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
-                                           int w, int h, NeG2& g)
+                                           int w, int h, NeG2& g, bool zf = false)
 {
-    const float fx = x + in.dx, fy = y + in.dy;
+    const float fx = x + (zf ? 0.f : in.dx), fy = y + (zf ? 0.f : in.dy);
     g.x1 = floor_f(fx); g.y1 = floor_f(fy);
     const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
     const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
@@ -148,9 +150,9 @@ __device__ __forceinline__ void ne_gather2(const float* __restrict__ R, unsigned
 }
 
 __device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x, int y, int w, int h, float sx, float sy,
-                                           float (&M)[5])
+                                           float (&M)[5], bool zf = false)
 {
-    const float dx = in.dx, dy = in.dy;
+    const float dx = zf ? 0.f : in.dx, dy = zf ? 0.f : in.dy;
     const int x1 = g.x1, y1 = g.y1;
     const float fx = (x + dx) - x1, fy = (y + dy) - y1;
     const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);

@@ -94,7 +94,8 @@ __device__ __forceinline__ unsigned next_buf(unsigned off, unsigned group, unsig
 // ------------------------------------------------------------------------------------------------------------------
 template <int W, int K, int G>
 __device__ __forceinline__ void role_vertical(const float* __restrict__ R, const float* __restrict__ flow,
-                                              double* __restrict__ buf, int p, int vw, int lane, int dbg, long long& fb_wait, int& fb_nbar)
+                                              double* __restrict__ buf, int p, int vw, int lane, int dbg, long long& fb_wait, int& fb_nbar,
+                                              bool zf)
 {
     using Ge = Geo<W, K, G>;
     constexpr int H = W, plane = W * H, NE = Ge::NE;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void role_vertical(const float* __restrict__ R, const
     unsigned goff = 0;                                  // group buffer being filled (offset in doubles)
 #pragma unroll
     for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
-    ne_gather2(R, r1base, in[0], x, row_of(0), W, H, g[0]);
+    ne_gather2(R, r1base, in[0], x, row_of(0), W, H, g[0], zf);
 
     // one entry: evaluate, refill the prefetch slots, update the running sums, publish the vsum row
     auto step = [&](int e, int kk, bool first, bool refill_g, bool refill_in) __attribute__((always_inline)) {
@@ -121,11 +122,11 @@ __device__ __forceinline__ void role_vertical(const float* __restrict__ R, const
         // the other one) and the inputs three entries ahead into the slot of entry e - 1, so nothing this entry still
         // needs is overwritten -- and the gather gets a whole row of lead instead of the tail of one (issued after the
         // arithmetic it had ~300 cycles before its use at the top of the next step: less than an L2 round trip).
-        if (refill_g && !(dbg & 4)) ne_gather2(R, r1base, in[(kk + 1) & 3], x, row_of(e + 1), W, H, g[(kk + 1) & 1]);
+        if (refill_g && !(dbg & 4)) ne_gather2(R, r1base, in[(kk + 1) & 3], x, row_of(e + 1), W, H, g[(kk + 1) & 1], zf);
         if (refill_in && !(dbg & 4)) ne_load(R, flow, r0base, flbase, x, row_of(e + 3), W, plane, in[(kk + 3) & 3]);
         __builtin_amdgcn_sched_barrier(0);
         float a[5];
-        ne_finish2(in[kk & 3], g[kk & 1], x, row_of(e), W, H, sx, border_factor(row_of(e), H), a);
+        ne_finish2(in[kk & 3], g[kk & 1], x, row_of(e), W, H, sx, border_factor(row_of(e), H), a, zf);
         if (first && kk == 0) {
 #pragma unroll
             for (int c = 0; c < 5; c++) vs[c] = (double)(a[c] * (float)(kM + 2));
@@ -379,7 +380,7 @@ __device__ __forceinline__ void role_solve(const float* __restrict__ R, const do
 
 template <int W, int K, int G>
 __global__ __launch_bounds__((64 * Geo<W, K, G>::NWAVES)) void k_fb_level(const float* __restrict__ R, float* __restrict__ flow,
-                                                                        int npairs, int iterations, int dbg_arg)
+                                                                        int npairs, int iterations, int dbg_arg, int zero_first)
 {
 #ifdef AVD_FB_DEBUG
     const int dbg = dbg_arg;                              // timing experiments (AVD_FB_DBG), see launch_fb_level
@@ -418,7 +419,7 @@ __global__ __launch_bounds__((64 * Geo<W, K, G>::NWAVES)) void k_fb_level(const 
         for (int it = 0; it < iterations; it++) {
             // flow rows cached in this CU's L1 during the previous iteration are stale now
             if (it > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            role_vertical<W, K, G>(R, flow, buf, p, ridx, lane, dbg, fb_wait, fb_nbar);
+            role_vertical<W, K, G>(R, flow, buf, p, ridx, lane, dbg, fb_wait, fb_nbar, zero_first && it == 0);
         }
     } else if (wave == smap) {
         __builtin_amdgcn_s_setprio(3);                    // its operands are rarely ready: take the slot when they are
@@ -436,16 +437,16 @@ __global__ __launch_bounds__((64 * Geo<W, K, G>::NWAVES)) void k_fb_level(const 
 }
 
 template <int W, int K, int G>
-void launch_one(hipStream_t stream, int grid, const float* R, float* flow, int np, int iterations, int dbg)
+void launch_one(hipStream_t stream, int grid, const float* R, float* flow, int np, int iterations, int dbg, int zero_first)
 {
-    hipLaunchKernelGGL((k_fb_level<W, K, G>), dim3(grid), dim3(64 * Geo<W, K, G>::NWAVES), 0, stream, R, flow, np, iterations, dbg);
+    hipLaunchKernelGGL((k_fb_level<W, K, G>), dim3(grid), dim3(64 * Geo<W, K, G>::NWAVES), 0, stream, R, flow, np, iterations, dbg, zero_first);
 }
 
 }  // namespace
 
 // one launch = all iterations of one pyramid level for `np` pairs; R = polynomial expansions of np + 1 frames
 // ([frame][y][x][5]), flow planar [pair][2][y][x] (initial flow in, final flow out)
-int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations)
+int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first)
 {
     if (np <= 0) return 0;
     const int grid = 8 * ((np + 7) / 8);
@@ -454,12 +455,12 @@ int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, flo
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();
     switch (w) {
     case 320:
-        if (var == 1) launch_one<320, 2, 2>(stream, grid, R, flow, np, iterations, dbg);      // A/B: two segments (slower)
-        else launch_one<320, 4, 2>(stream, grid, R, flow, np, iterations, dbg);
+        if (var == 1) launch_one<320, 2, 2>(stream, grid, R, flow, np, iterations, dbg, zero_first);      // A/B: two segments (slower)
+        else launch_one<320, 4, 2>(stream, grid, R, flow, np, iterations, dbg, zero_first);
         break;
-    case 160: launch_one<160, 2, 4>(stream, grid, R, flow, np, iterations, dbg); break;
-    case 80: launch_one<80, 1, 4>(stream, grid, R, flow, np, iterations, dbg); break;
-    case 40: launch_one<40, 1, 4>(stream, grid, R, flow, np, iterations, dbg); break;
+    case 160: launch_one<160, 2, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first); break;
+    case 80: launch_one<80, 1, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first); break;
+    case 40: launch_one<40, 1, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first); break;
     default: ctx->err = "launch_fb_level: unsupported level size"; return AVD_ERR_ARG;
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -199,4 +199,5 @@ int comm_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int coun
 // avd_audio.hip: per-window features of a mono float32 waveform (device pointers)
 int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, avd_audio_window* d_out, int nwin);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
-int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations);
+// zero_first: the initial flow is zero whatever the buffer holds (the coarsest level: no clearing launch)
+int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first);
