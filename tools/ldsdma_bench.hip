@@ -34,6 +34,50 @@ __global__ __launch_bounds__(512) void k_fill(const char* __restrict__ small, si
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// the same traffic through ordinary loads: 16 bytes per lane into registers (global_load_dwordx4), DEPTH loads in flight
+template <int DEPTH>
+__global__ __launch_bounds__(512) void k_vgpr(const char* __restrict__ small, size_t small_bytes, const char* __restrict__ big,
+                                             size_t big_bytes, int pieces, int mix)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wid = (size_t)blockIdx.x * 8 + wave, nw = (size_t)gridDim.x * 8;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < pieces; i0 += DEPTH) {
+        f4 v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int i = i0 + d;
+            const size_t seq = (size_t)i * nw + wid;
+            const bool from_big = mix == 1 || mix == 4 || (mix == 2 && (i % 3) == 0);
+            const char* src = from_big ? big + (seq * 1024) % big_bytes
+                                       : small + (((size_t)i * 8 + wave + (size_t)blockIdx.x * 37) * 1024) % small_bytes;
+            v[d] = *reinterpret_cast<const f4*>(src + lane * 16);
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) acc += v[d];
+    }
+    if (acc[0] == 123.456f) reinterpret_cast<f4*>(const_cast<char*>(big))[threadIdx.x] = acc;    // never true: keeps the loads
+}
+
+template <int DEPTH>
+void run_vgpr(const char* name, int mix, const char* small, size_t sb, const char* big, size_t bb, int cus)
+{
+    const int pieces = 4096;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_vgpr<DEPTH>, dim3(cus), dim3(512), 0, 0, small, sb, big, bb, pieces, mix);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_vgpr<DEPTH>, dim3(cus), dim3(512), 0, 0, small, sb, big, bb, pieces, mix);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = 3.0 * cus * 8 * pieces * 1024.0;
+    printf("%-34s depth %2d: %7.2f TB/s  (%5.1f GB/s per CU)   [loads into registers]\n", name, DEPTH, bytes / (ms * 1e-3) / 1e12,
+           bytes / (ms * 1e-3) / 1e9 / cus);
+}
+
 template <int DEPTH>
 void run(const char* name, int mix, const char* small, size_t sb, const char* big, size_t bb, int cus)
 {
@@ -72,5 +116,9 @@ int main()
     run<12>("64 MiB buffer (Infinity Cache)", 4, small, sb, big, (size_t)64 << 20, cus);
     run<12>("1 : 2 mix (GEMM-like)", 2, small, sb, big, bb, cus);
     run<16>("1 : 2 mix (GEMM-like)", 2, small, sb, big, bb, cus);
+    run_vgpr<8>("all workgroups, one small buffer", 0, small, sb, big, bb, cus);
+    run_vgpr<16>("all workgroups, one small buffer", 0, small, sb, big, bb, cus);
+    run_vgpr<16>("large buffer streamed once", 1, small, sb, big, bb, cus);
+    run_vgpr<16>("1 : 2 mix (GEMM-like)", 2, small, sb, big, bb, cus);
     return 0;
 }
