@@ -307,12 +307,16 @@ __device__ __forceinline__ void role_solve(const float* __restrict__ R, const do
     // solver 0 touches R0 and the x flow plane, solver 1 R1 and the y plane
     const char* rsrc = reinterpret_cast<const char*>(R + ((size_t)p + xi) * 5 * plane);
     const char* fsrc = reinterpret_cast<const char*>(fl + (size_t)xi * plane);
-    constexpr int RL = (G * W * 20 + 1023) / 1024, FL = (G * W * 4 + 1023) / 1024;
+    // Touch loads: ONE dword per 128-byte line (a wave instruction covers 64 lines = 8 KiB of the buffer).  The point of a
+    // touch is the HBM / Infinity Cache -> L2 fetch of the line; what comes back to the CU is thrown away, and a CU ingests
+    // only ~40-60 GB/s (tools/ldsdma_bench.hip) -- of which this kernel's vertical waves need ~40: whole-row touches
+    // (16 bytes per lane) took a third of that path for bytes nobody uses.
+    constexpr int RL = (G * W * 20 + 8191) / 8192, FL = (G * W * 4 + 8191) / 8192;
     // touch loads in flight: issued in one barrier interval, retired (values discarded) TWO intervals later -- an
     // interval (~1.5 us at W = 320) is shorter than a loaded HBM round trip, and the solver must never wait for them
-    flt4 tv[2][RL + FL];
+    float tv[2][RL + FL];
 #pragma unroll
-    for (int i = 0; i < 2 * (RL + FL); i++) tv[i / (RL + FL)][i % (RL + FL)] = flt4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2 * (RL + FL); i++) tv[i / (RL + FL)][i % (RL + FL)] = 0.f;
     auto touch_retire = [&](int par) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RL + FL; i++) asm volatile("" ::"v"(tv[par][i]));
@@ -327,13 +331,13 @@ __device__ __forceinline__ void role_solve(const float* __restrict__ R, const do
         const unsigned rbeg = (unsigned)y0 * W * 20u, fbeg = (unsigned)y0 * W * 4u;
 #pragma unroll
         for (int i = 0; i < RL; i++) {
-            const unsigned o = (unsigned)i * 1024u + (unsigned)lane * 16u;
-            tv[par][i] = *reinterpret_cast<const flt4*>(rsrc + rbeg + (o < rbytes ? o : rbytes - 16u));
+            const unsigned o = (unsigned)i * 8192u + (unsigned)lane * 128u;
+            tv[par][i] = *reinterpret_cast<const float*>(rsrc + rbeg + (o < rbytes ? o : rbytes - 4u));
         }
 #pragma unroll
         for (int i = 0; i < FL; i++) {
-            const unsigned o = (unsigned)i * 1024u + (unsigned)lane * 16u;
-            tv[par][RL + i] = *reinterpret_cast<const flt4*>(fsrc + fbeg + (o < fbytes ? o : fbytes - 16u));
+            const unsigned o = (unsigned)i * 8192u + (unsigned)lane * 128u;
+            tv[par][RL + i] = *reinterpret_cast<const float*>(fsrc + fbeg + (o < fbytes ? o : fbytes - 4u));
         }
     };
     unsigned goff = 0;

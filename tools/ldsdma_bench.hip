@@ -97,11 +97,11 @@ void run(const char* name, int mix, const char* small, size_t sb, const char* bi
     printf("%-34s depth %2d: %7.2f TB/s  (%5.1f GB/s per CU)\n", name, DEPTH, bytes / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 1e9 / cus);
 }
 
-int main()
+int main(int argc, char** argv)
 {
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
-    const int cus = p.multiProcessorCount;
+    const int cus = argc > 1 ? atoi(argv[1]) : p.multiProcessorCount;     // workgroups (one per CU); fewer = part of the chip
     const size_t sb = 1179648, bb = (size_t)768 << 20;      // 1.1 MiB (a 768 x 768 bf16 weight), 768 MiB
     char *small, *big;
     CHECK(hipMalloc(&small, sb)); CHECK(hipMalloc(&big, bb));
