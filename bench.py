@@ -85,10 +85,11 @@ def roofline_objects(n, h, w, stage, latency_ms):
         "traffic": pmc.get("k_fb_level<320>", {}).get("hbm_bytes"),
         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(fb_ms, 4), "launches_per_step": 1,
         "share_of_step": round(fb_ms / latency_ms, 4) if latency_ms > 0 else 0.0,
-        "bound_note": "measured (in-kernel stamps, profiles/r02_experiments.md): the kernel is bound by VALU issue of the "
-                      "exact normal equations and by the dependent double-add chain of the horizontal scan, not by HBM -- the "
+        "bound_note": "measured (in-kernel stamps, ablations, tools/ldsdma_bench.hip; profiles/r02_experiments.md): the kernel is bound by "
+                      "VALU issue of the exact normal equations (two vertical waves per SIMD), by the dependent double-add chain of "
+                      "the horizontal scan and by what ONE CU can ingest from L2 (~40-60 GB/s; it pulls ~29), not by HBM -- the "
                       "fraction of HBM peak is low BY CONSTRUCTION: 80 of the 136 B per pixel and iteration of the two-kernel "
-                      "path (the double intermediate D) no longer exist",
+                      "path (the double intermediate D) no longer exist, and the kernel holds 119 of the 256 CUs",
         "valu": {"flops": round(flops), "tflops": round(flops / (fb_ms * 1e-3) / 1e12, 2) if fb_ms > 0 else 0.0,
                  "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF},
         "timed": "HIP events around the launch on the library's stream, clips run alone before the timed region",
