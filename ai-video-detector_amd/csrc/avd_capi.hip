@@ -45,7 +45,7 @@ void free_ws(Workspace& ws)
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap); F(ws.d_lap_part);
     F(ws.d_tables);
-    for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); }
+    for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); F(ws.d_flow2[k]); }
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
@@ -152,18 +152,24 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
 int avd_ws_reserve_fb(avd_ctx* ctx, int n)
 {
     Workspace& ws = ctx->ws;
-    if (ws.d_vs) return 0;
     const size_t nf = kFbChunk + 2, np = kFbChunk;       // +1 frame: the two segments of a chunk overlap by one frame
-    for (int k = 0; k < AVD_FB_LEVELS; k++) {
-        const size_t plane = (size_t)(AVD_SMALL >> k) * (AVD_SMALL >> k);
-        if (int e = dev_alloc(ctx, ws.d_pyr[k], nf * plane)) return e;
-        if (int e = dev_alloc(ctx, ws.d_poly[k], nf * 5 * plane)) return e;
-        if (int e = dev_alloc(ctx, ws.d_flow[k], np * 2 * plane)) return e;
+    if (!ws.d_part) {                                    // d_part is allocated last: set = everything below exists
+        for (int k = 0; k < AVD_FB_LEVELS; k++) {
+            const size_t plane = (size_t)(AVD_SMALL >> k) * (AVD_SMALL >> k);
+            if (int e = dev_alloc(ctx, ws.d_pyr[k], nf * plane)) return e;
+            if (int e = dev_alloc(ctx, ws.d_poly[k], nf * 5 * plane)) return e;
+            if (int e = dev_alloc(ctx, ws.d_flow[k], np * 2 * plane)) return e;
+            if (int e = dev_alloc(ctx, ws.d_flow2[k], np * 2 * plane)) return e;
+        }
+        if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
+        if (int e = dev_alloc(ctx, ws.d_part, np * 2 * 16)) return e;
     }
-    if (int e = dev_alloc(ctx, ws.d_vs0, np * 5 * AVD_SMALL * 8)) return e;
-    if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
-    if (int e = dev_alloc(ctx, ws.d_part, np * 2 * 16)) return e;
-    if (int e = dev_alloc(ctx, ws.d_vs, np * (5 * AVD_NPIX + 512))) return e;      // + one pad tile per pair
+    // the double intermediate of the two-kernel fallback (525 MB): only when that path is selected
+    const bool two_kernel = ctx->fb_mode == 0 && ctx->fb_fused != 0xF;
+    if (two_kernel && !ws.d_vs) {
+        if (int e = dev_alloc(ctx, ws.d_vs0, np * 5 * AVD_SMALL * 8)) return e;
+        if (int e = dev_alloc(ctx, ws.d_vs, np * (5 * AVD_NPIX + 512))) return e;      // + one pad tile per pair
+    }
     (void)n;
     return 0;
 }
@@ -278,6 +284,7 @@ static int impl_create(int device_id, avd_ctx** out)
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->num_cus = prop.multiProcessorCount;
         if (const char* e = std::getenv("AVD_FB_FUSED")) ctx->fb_fused = (int)std::strtol(e, nullptr, 0) & 0xF;
+        if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
         build_fb_consts(ctx->fbc);
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
              hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;
@@ -558,7 +565,7 @@ static int64_t impl_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_
     // the Farneback scratch holds ONE chunk (kFbChunk pairs): for longer clips these are the last chunk's buffers
     else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)std::min(n, kFbChunk + 1) * (AVD_NPIX >> (2 * k)) * 4; }
     else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)std::min(n, kFbChunk + 1) * 5 * (AVD_NPIX >> (2 * k)) * 4; }
-    else if ((k = level("flow")) >= 0) { src = ws.d_flow[k]; bytes = (size_t)std::min(std::max(n - 1, 0), kFbChunk) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("flow")) >= 0) { src = ws.flow_res[k] ? ws.flow_res[k] : ws.d_flow[k]; bytes = (size_t)std::min(std::max(n - 1, 0), kFbChunk) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
     else if (std::strcmp(name, "vs0") == 0) { src = ws.d_vs0; bytes = (size_t)kFbChunk * 5 * AVD_SMALL * 8 * 8; }
     else { ctx->err = "unknown debug buffer"; return AVD_ERR_ARG; }
     if (!src) { ctx->err = "buffer not allocated yet"; return AVD_ERR_ARG; }
@@ -596,6 +603,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
 {
     if (!ctx || !name) return AVD_ERR_ARG;
     if (std::strcmp(name, "fb_fused") == 0) { ctx->fb_fused = value & 0xF; return AVD_OK; }
+    if (std::strcmp(name, "fb_mode") == 0) { ctx->fb_mode = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
     ctx->err = std::string("unknown option: ") + name;
     return AVD_ERR_ARG;

@@ -881,8 +881,8 @@ static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_of
         g.flow[k] = ws.d_flow[k] + (size_t)pair_off * 2 * plane;
     }
     g.prof = ctx->profiling && pair_off == 0 ? ctx : nullptr;
-    g.vs = ws.d_vs + (size_t)pair_off * (5 * AVD_NPIX + 512);
-    g.vs0 = ws.d_vs0 + (size_t)pair_off * 5 * S * 8;
+    g.vs = ws.d_vs ? ws.d_vs + (size_t)pair_off * (5 * AVD_NPIX + 512) : nullptr;
+    g.vs0 = ws.d_vs0 ? ws.d_vs0 + (size_t)pair_off * 5 * S * 8 : nullptr;
     g.stats = ws.d_stats + (size_t)pair_off * 2;
     g.part = ws.d_part + (size_t)pair_off * 2 * 16;
     g.flow_il = ws.d_flow_il ? ws.d_flow_il + (size_t)pair_off * AVD_NPIX * 2 : nullptr;
@@ -962,11 +962,26 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             if (!((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
         } else {
             const int items = np * 2 * h * (w / 4);
-            const float* prev = g.flow[k + 1];
+            const float* prev = ctx->ws.flow_res[k + 1];
             if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
             else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
             else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
         }
+        ctx->ws.flow_res[k] = g.flow[k];
+        if (ctx->fb_mode == 1) {
+            // fast level kernel (avd_fbfast.hip): one launch per iteration, the flow ping-pongs between the level's two buffers
+            float* a = g.flow[k];
+            float* b = ctx->ws.d_flow2[k] + (size_t)pair_off * 2 * plane;
+            if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
+            for (int it = 0; it < 3; it++) {
+                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], a, b, np, k == AVD_FB_LEVELS - 1 && it == 0)) return e;
+                float* t = a; a = b; b = t;
+            }
+            if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
+            ctx->ws.flow_res[k] = a;                       // after the last swap `a` is the buffer written last
+            continue;
+        }
+        if (!((ctx->fb_fused >> k) & 1) && !g.vs) { ctx->err = "two-kernel Farneback path: scratch not reserved"; return AVD_ERR_ARG; }
         // ctx->fb_fused (AVD_FB_FUSED / avd_set_option "fb_fused"): bit k set = level k runs the fused kernel (avd_fbfused.hip: all three iterations in one launch,
         // D never leaves the chip); clear = the two-kernel path below
         if ((ctx->fb_fused >> k) & 1) {
@@ -993,7 +1008,7 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
     if (n < 2) return 0;
     const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     const int np = n - 1;
-    const float* fl = g.flow[0];
+    const float* fl = ctx->ws.flow_res[0] ? ctx->ws.flow_res[0] : g.flow[0];
     hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
     hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
     hipLaunchKernelGGL(k_stats_final, dim3((np + 63) / 64), dim3(64), 0, stream, (const float*)g.part, g.stats, np);

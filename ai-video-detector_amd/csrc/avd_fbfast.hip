@@ -1,0 +1,393 @@
+// avd_fbfast.hip -- FarnebackUpdateFlow_Blur (winsize 15), ONE iteration per launch, a pair spread over several
+// workgroups, no serial horizontal chain (gfx950).  The default level kernel since round 3 ("fb_mode" = fast).
+//
+// Reference site: cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.2, 0), app/analyzers/video.py:45.
+//
+// What is literal and what is not.  cv2 forms the 15 x 15 box sums of the five normal-equation channels as RUNNING sums:
+//   vertical    vsum[x] += (float)(M[y+7][x] - M[y-8][x])      a float difference added to a double, per column
+//   horizontal  g       += (vsum[x+7] - vsum[x-8])             doubles
+// The vertical chain rounds a FLOAT at every slide, so its value at row y depends on every row above: re-ordering it moves
+// the flow by up to 8e-5 px on hard inputs (tools/experiments/fb_tolerance_exp.c, mode 2).  It is kept literal here: one
+// "chain" wave per 64 columns walks down the rows exactly as cv2 does (lanes along x: the chain is sequential in y only).
+// The horizontal chain only ever adds doubles; forming each window directly, sum of vsum[x-7 .. x+7] in double, differs from
+// cv2's running value by a few double ulps (1e-16 relative), which the float cast of the flow swallows: on every input of
+// that experiment (smooth clips, scene cuts, white noise, flat boxes) the flow comes out BIT-IDENTICAL to the oracle
+// (mode 1: max |delta| = 0; 3e-14 px on a degenerate flat image).  tests/test_gpu_fbfast.py bounds it at 1e-5 px and
+// ai_susp at 1e-6 on every geometry the parity suite covers; avd_fbfused.hip stays as fb_mode = exact.
+//
+// Structure.  The serial scanner wave of avd_fbfused.hip (one wave of 40 lanes walking a dependent double chain over 320
+// columns, the pole of that kernel) is gone, and with it the 160 KB transpose buffer that held a workgroup to one per CU
+// and a pair to one workgroup.  A workgroup owns a STRIP of a pair: OW output columns plus 7 halo columns on each side
+// (recomputed, not exchanged: there is no cross-workgroup dependency inside a launch), all rows.  Columns outside the image
+// clamp to the edge column, which is exactly cv2's replicated border of vsum.  Per 64-column block of the strip four waves:
+//   N0, N1  normal equations (FarnebackUpdateMatrices) of two image rows each per step -> M ring in LDS (float)
+//   C       the literal vertical chain: M rows in, vsum rows (double) out to LDS
+//   X       horizontal window sums + 2 x 2 solve + flow stores.  A lane owns FOUR consecutive columns of one row: 18
+//           doubles (nine 16-byte LDS reads) per channel give four windows with 21 additions, and a wave covers 4 rows x 64
+//           columns per step
+// (No touch / prefetch loads: the N waves' own three-entry lead covers the latency, and touching the next rows one dword
+// per line from a fourth wave cost 0.16 ms per level: it is the texture-addresser / L1 path that limits this kernel.)
+// One workgroup barrier per step of 4 rows; N works on group t, C on group t-1, X on group t-2.  A launch is one blur
+// iteration: the flow is read from one buffer and written to another (strips of a pair read each other's columns), and the
+// next iteration is the next launch.
+//
+// Bound: HBM.  Per iteration every frame's R is read once (20 B/px; pair p's R1 is pair p+1's R0 and neighbouring pairs
+// share an XCD's L2), the flow is read and written (16 B/px per pair): 441 MB at 320 px x 119 pairs.
+#include <cstdio>
+#include <cstdlib>
+#include "avd_internal.h"
+#include "avd_fb_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kM = 7;                 // (winsize - 1) / 2
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+template <int W, int NB>
+struct FGeo {
+    static constexpr int H = W;
+    static constexpr int SW = 64 * NB;               // lane columns of a strip
+    static constexpr int NWAVES = 4 * NB;
+    static constexpr int NE = H + kM;                // entries of the vertical chain: image row min(e, H-1)
+    static constexpr int NG = (NE + 3) / 4;          // groups of four entries
+    static constexpr int T = ((NG + 2 + 3) / 4) * 4; // steps (= barriers): N on group t, C on t-1, X on t-2; the loops unroll by 4
+    static constexpr int ROWLEN = SW + 18;           // doubles per (row slot, channel) line; ROWLEN % 4 == 2: the four rows
+                                                     // of a solver instruction fall on different halves of a 32-byte bank pair
+    static constexpr int VS_SLOT = 5 * ROWLEN;
+    static constexpr int VS_DOUBLES = 8 * VS_SLOT;   // ring of 8 image rows of vsum
+    static constexpr int M_SLOT = 5 * 64;            // floats of one row of one block
+    static constexpr int M_FLOATS = NB * 8 * M_SLOT; // ring of 8 rows per block
+    static constexpr int LDS_DOUBLES = VS_DOUBLES + M_FLOATS / 2;
+    static_assert(ROWLEN % 4 == 2 && LDS_DOUBLES * 8 <= 163840, "LDS layout");
+    static_assert(H % 4 == 0, "whole groups of image rows");
+};
+
+// workgroup barrier; debug builds (-DAVD_FBF_DEBUG) account the cycles a wave spends waiting at it
+#ifdef AVD_FBF_DEBUG
+__device__ long long g_fbf_stamps[16][3];               // [wave][total cycles, cycles at barriers, role] of workgroup 0
+#define fb_barrier()                                                      \
+    do {                                                                  \
+        const long long t0__ = __builtin_amdgcn_s_memtime();              \
+        __syncthreads();                                                  \
+        fbf_wait += __builtin_amdgcn_s_memtime() - t0__;                  \
+    } while (0)
+#define FBF_WAIT_DECL long long fbf_wait = 0;
+#define FBF_WAIT_OUT(w, role, t0)                                                           \
+    if (blockIdx.x == 8 && (threadIdx.x & 63) == 0) {                                       \
+        g_fbf_stamps[w][0] = __builtin_amdgcn_s_memtime() - (t0);                           \
+        g_fbf_stamps[w][1] = fbf_wait;                                                      \
+        g_fbf_stamps[w][2] = role;                                                          \
+    }
+#else
+__device__ __forceinline__ void fb_barrier() { __syncthreads(); }
+#define FBF_WAIT_DECL
+#define FBF_WAIT_OUT(w, role, t0)
+#endif
+
+// ------------------------------------------------------------------------------------------------------------------
+// N: normal equations of entries 4t + 2k, 4t + 2k + 1 at step t (k = 0, 1), columns of one block.
+// ------------------------------------------------------------------------------------------------------------------
+// GD = entries of lead of the bilinear gather of R1 (its address needs the flow, so it cannot be issued arbitrarily early):
+// the gather of entry i + GD is issued while entry i is evaluated, the inputs (flow, R0) of entry i + 2 GD + 1 likewise.
+// Slots are statically indexed: the loop body is GD + 1 steps = 2 (GD + 1) entries.
+template <int W, int NB, int GD>
+__device__ __forceinline__ void role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
+                                        int p, int x, int k, int lane, bool zf)
+{
+    using Ge = FGeo<W, NB>;
+    FBF_WAIT_DECL
+#ifdef AVD_FBF_DEBUG
+    const long long fbf_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr int H = W, plane = W * H;
+    constexpr int NGS = GD + 1, NIS = 2 * NGS, U = NGS;   // gather slots, input slots, steps per loop body
+    const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
+    const float sx = border_factor(x, W);
+    auto ent = [&](int i) { return 4 * (i >> 1) + 2 * k + (i & 1); };      // this wave's i-th entry
+    auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
+    NeIn in[NIS];
+    NeG2 g[NGS];
+#pragma unroll
+    for (int i = 0; i < NIS - 1; i++) ne_load(R, flow, r0base, flbase, x, row_of(ent(i)), W, plane, in[i]);
+#pragma unroll
+    for (int i = 0; i < GD; i++) ne_gather2(R, r1base, in[i], x, row_of(ent(i)), W, H, g[i], zf);
+    auto work = [&](int t, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i = 2 * t + j, ii = 2 * q + j;                         // ii = i mod NIS, static
+            const int e = ent(i);
+            // refills first: the gather GD entries ahead goes into the slot the previous entry released, the inputs
+            // NIS - 1 entries ahead into the slot of the entry before this one (rows beyond the image clamp to the last)
+#ifndef AVD_FBF_NOGATHER          // timing-only ablation builds (results are wrong)
+            ne_gather2(R, r1base, in[(ii + GD) % NIS], x, row_of(ent(i + GD)), W, H, g[(ii + GD) % NGS], zf);
+#endif
+#ifndef AVD_FBF_NOINLOAD
+            ne_load(R, flow, r0base, flbase, x, row_of(ent(i + NIS - 1)), W, plane, in[(ii + NIS - 1) % NIS]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            float a[5];
+            ne_finish2(in[ii % NIS], g[ii % NGS], x, e, W, H, sx, border_factor(e, H), a, zf);
+            float* dst = mring + (e & 7) * Ge::M_SLOT + lane;
+#pragma unroll
+            for (int c = 0; c < 5; c++) dst[c * 64] = a[c];
+        }
+    };
+    constexpr int TN = H / 4;                              // steps that bring image rows in; the rest only keep the barrier count
+    int t0 = 0;
+    for (; t0 + U <= TN; t0 += U) {
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            fb_barrier();
+            work(t0 + q, q);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TN % U; q++) {
+        fb_barrier();
+        work(t0 + q, q);
+    }
+    for (int t = TN; t < Ge::T; t++) fb_barrier();
+    FBF_WAIT_OUT(threadIdx.x >> 6, k, fbf_t0)
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C: cv2's vertical running sums, literally.  Entry e brings image row min(e, H-1) in; from e = 7 on, row e - 15 (row 0
+// while the window still touches the top edge) leaves and the vsum row of image row e - 7 is published.
+// ------------------------------------------------------------------------------------------------------------------
+template <int W, int NB>
+__device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, int b, int lane)
+{
+    using Ge = FGeo<W, NB>;
+    FBF_WAIT_DECL
+#ifdef AVD_FBF_DEBUG
+    const long long fbf_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr int H = W;
+    float ring[16][5];                                   // ring[e & 15] = M row of entry e (statically indexed)
+    double vs[5] = {0., 0., 0., 0., 0.};
+    double* vdst = vsring + 8 + 64 * b + lane;
+    for (int t4 = 0; t4 < Ge::T; t4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t = t4 + q;
+            fb_barrier();
+            if (t >= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = 4 * (t - 1) + j;
+                    const int kk = 4 * ((q + 3) & 3) + j;                    // e & 15, static
+                    if (e < Ge::NE) {                                        // wave-uniform
+                        const int er = e < H - 1 ? e : H - 1;
+                        const float* src = mring + (er & 7) * Ge::M_SLOT + lane;
+                        float a[5];
+#pragma unroll
+                        for (int c = 0; c < 5; c++) a[c] = src[c * 64];
+                        if (e == 0) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) vs[c] = (double)(a[c] * (float)(kM + 2));
+                        } else if (e < kM) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) vs[c] += (double)a[c];
+                        } else {
+                            const bool top = e < 16;                         // the leaving row is still row 0
+#pragma unroll
+                            for (int c = 0; c < 5; c++) {
+                                const float lv = top ? ring[0][c] : ring[(kk + 1) & 15][c];
+                                vs[c] += (double)(a[c] - lv);
+                            }
+                            double* d = vdst + ((e - kM) & 7) * Ge::VS_SLOT;
+#pragma unroll
+                            for (int c = 0; c < 5; c++) d[c * Ge::ROWLEN] = vs[c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 5; c++) ring[kk][c] = a[c];
+                    }
+                }
+            }
+        }
+    }
+    FBF_WAIT_OUT(threadIdx.x >> 6, 2, fbf_t0)
+}
+
+// 1 / d as the compiler's IEEE division sequence computes it (v_rcp_f64, two Newton steps, a correction of the quotient)
+// minus its scaling and fix-up instructions: they only act on denormal / huge / special operands, and d is a determinant
+// plus 1e-3 in [1e-3, ~1e13].  Same result as 1. / d, bit for bit, on that range (tests/test_gpu_fbfast.py compares the
+// flow of the exact kernels, which divide, against this one).
+__device__ __forceinline__ double recip_exact(double d)
+{
+#ifdef AVD_FBF_PLAIN_DIV
+    return 1. / d;
+#else
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e0 = __builtin_fma(-d, r0, 1.);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-d, r1, 1.);
+    const double r2 = __builtin_fma(r1, e1, r1);
+    const double q = 1. * r2;
+    const double e2 = __builtin_fma(-d, q, 1.);
+    return __builtin_fma(e2, r2, q);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// X: window sums of 15 columns, 2 x 2 solve (double, cv2's operation order), flow stores.  Lane = (row r of the group,
+// chunk of four output columns).  The strip's lane column u holds image column clamp(xlo + u) with xlo = o0 - 7, and vsum
+// of lane column u sits at index u + 8 of its line: the window of output column o0 + i is lane columns i .. i + 14.
+// ------------------------------------------------------------------------------------------------------------------
+template <int W, int NB>
+__device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, int p, int b, int lane, int o0, int ow)
+{
+    using Ge = FGeo<W, NB>;
+    FBF_WAIT_DECL
+#ifdef AVD_FBF_DEBUG
+    const long long fbf_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr int H = W, plane = W * H;
+    const double scale = 1. / (15 * 15);
+    const int r = lane >> 4, j = 16 * b + (lane & 15);
+    const bool colok = 4 * j < ow;
+    float* fl = flow_out + (size_t)p * 2 * plane + o0 + 4 * j;
+    const double* vsrc = vsring + 8 + 4 * j;
+    for (int t4 = 0; t4 < Ge::T; t4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t = t4 + q;
+            fb_barrier();
+            const int y = 4 * t - 15 + r;
+#ifdef AVD_FBF_NOSOLVE
+            if (false) {
+#else
+            if (t >= 2 && colok && y >= 0 && y < H) {
+#endif
+                const dbl2* s = reinterpret_cast<const dbl2*>(vsrc + (y & 7) * Ge::VS_SLOT);
+                double o[5][4];
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    double v[18];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        const dbl2 w2 = s[c * (Ge::ROWLEN / 2) + i];
+                        v[2 * i] = w2.x; v[2 * i + 1] = w2.y;
+                    }
+                    double A = v[3];
+#pragma unroll
+                    for (int i = 4; i < 15; i++) A += v[i];
+                    const double p12 = v[1] + v[2], q2 = v[15] + v[16];
+                    o[c][0] = A + (v[0] + p12);
+                    o[c][1] = A + (p12 + v[15]);
+                    o[c][2] = A + (v[2] + q2);
+                    o[c][3] = A + (q2 + v[17]);
+                }
+                float fx[4], fy[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double g11 = o[0][i] * scale, g12 = o[1][i] * scale, g22 = o[2][i] * scale;
+                    const double h1 = o[3][i] * scale, h2 = o[4][i] * scale;
+                    const double idet = recip_exact(g11 * g22 - g12 * g12 + 1e-3);
+                    fx[i] = (float)((g11 * h2 - g12 * h1) * idet);
+                    fy[i] = (float)((g22 * h1 - g12 * h2) * idet);
+                }
+                float* dst = fl + y * W;
+                *reinterpret_cast<float4*>(dst) = make_float4(fx[0], fx[1], fx[2], fx[3]);
+                *reinterpret_cast<float4*>(dst + plane) = make_float4(fy[0], fy[1], fy[2], fy[3]);
+            }
+        }
+    }
+    FBF_WAIT_OUT(threadIdx.x >> 6, 3, fbf_t0)
+}
+
+// NB = 2: 8 waves, 66 KiB of LDS -> two workgroups per CU (4 waves per SIMD: at most 128 registers)
+template <int W, int NB, int GD>
+__global__ __launch_bounds__((64 * FGeo<W, NB>::NWAVES), (NB == 2 && W == 320 ? 4 : 1)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
+                                                                      float* __restrict__ flow_out, int npairs, int nstrips, int ow,
+                                                                      int zero_first, int dbg)
+{
+    using Ge = FGeo<W, NB>;
+    __shared__ __align__(16) double lds[Ge::LDS_DOUBLES];
+    double* vsring = lds;
+    float* mrings = reinterpret_cast<float*>(lds + Ge::VS_DOUBLES);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (XCD group, pair inside the group, strip): an XCD's L2 serves a contiguous run of pairs -- pair p gathers as R1 the
+    // frame pair p + 1 reads as R0 -- and all strips of a pair; workgroups are dealt round-robin to the 8 XCDs
+    const int ppx = (npairs + 7) >> 3;
+    const int local = blockIdx.x >> 3;
+    const int p = (blockIdx.x & 7) * ppx + local / nstrips;
+    const int s = local % nstrips;
+    if (p >= npairs) return;                              // whole workgroup
+    const int o0 = s * ow;
+    const int width = o0 + ow <= W ? ow : W - o0;         // output columns of this strip (multiples of 4)
+    // Waves w, w + 4, w + 8 of a workgroup share a SIMD.  Issue cycles per step: X ~ 900 (double), N ~ 550, C ~ 230: with
+    // NB = 3 the SIMDs get {X, N1, C} of block 0, 1, 2 and {N0, N0, N0} -- 1700 / 1700 / 1700 / 1650 cycles
+    int b, role;
+    if (NB == 3) {
+        const int pos = wave & 3, grp = wave >> 2;
+        b = pos == 3 ? grp : pos;
+        role = pos == 3 ? 0 : (grp == 0 ? 3 : (grp == 1 ? 1 : 2));
+    } else {
+        b = wave >> 2;
+        role = (wave + b) & 3;                            // rotate the roles over a block's four waves: every SIMD gets a mix
+    }
+    const int xu = o0 - kM + 64 * b + lane;               // image column of this lane (clamped: replicated border)
+    const int x = xu < 0 ? 0 : (xu > W - 1 ? W - 1 : xu);
+    float* mring = mrings + b * 8 * Ge::M_SLOT;
+    if (role < 2) {
+        role_ne<W, NB, GD>(R, flow_in, mring, p, x, role, lane, zero_first != 0);
+    } else if (role == 2) {
+        if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
+        role_chain<W, NB>(mring, vsring, b, lane);
+    } else {
+        role_solve<W, NB>(vsring, flow_out, p, b, lane, o0, width);
+    }
+}
+
+template <int W, int NB, int GD = 1>
+void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, int np, int nstrips, int ow, int zero_first)
+{
+    const int grid = 8 * ((np + 7) / 8) * nstrips;
+    static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
+    hipLaunchKernelGGL((k_fb_fast<W, NB, GD>), dim3(grid), dim3(64 * FGeo<W, NB>::NWAVES), 0, stream, R, fin, fout, np, nstrips, ow, zero_first, dbg);
+}
+
+}  // namespace
+
+// ONE blur iteration of one pyramid level for `np` pairs: flow_in -> flow_out (different buffers), R = polynomial expansions
+// of np + 1 frames ([frame][y][x][5]), flows planar [pair][2][y][x]
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int np, int zero_first)
+{
+    if (np <= 0) return 0;
+    if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
+    static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
+    switch (w) {
+    case 320:
+        if (var == 1) launch_fast<320, 3, 1>(stream, R, flow_in, flow_out, np, 2, 160, zero_first);
+        else if (var == 2) launch_fast<320, 3, 3>(stream, R, flow_in, flow_out, np, 2, 160, zero_first);
+        else launch_fast<320, 3, 2>(stream, R, flow_in, flow_out, np, 2, 160, zero_first);
+        break;
+    case 160:
+        if (var == 1) launch_fast<160, 2, 1>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
+        else launch_fast<160, 2, 2>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
+        break;
+    case 80: launch_fast<80, 2>(stream, R, flow_in, flow_out, np, 1, 80, zero_first); break;
+    case 40: launch_fast<40, 1>(stream, R, flow_in, flow_out, np, 1, 40, zero_first); break;
+    default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+#ifdef AVD_FBF_DEBUG
+    static const int stamps_w = [] { const char* e = std::getenv("AVD_FBF_STAMPS"); return e ? std::atoi(e) : 0; }();
+    static int printed = 0;
+    if (stamps_w == w && printed++ == 10) {
+        long long h[16][3];
+        (void)hipStreamSynchronize(stream);
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fbf_stamps), sizeof(h)) == hipSuccess)
+            for (int i = 0; i < 16; i++)
+                if (h[i][0])
+                    fprintf(stderr, "fbfast stamps w=%d wave %2d role %lld: total %lld cycles, at barriers %lld (%.1f %%)\n", w, i, h[i][2], h[i][0],
+                            h[i][1], 100. * h[i][1] / h[i][0]);
+    }
+#endif
+    return 0;
+}

@@ -104,6 +104,8 @@ struct Workspace {
     float* d_pyr[AVD_FB_LEVELS] = {};     // [n][hL*wL]
     float* d_poly[AVD_FB_LEVELS] = {};    // [n][hL*wL][5] interleaved polynomial coefficients
     float* d_flow[AVD_FB_LEVELS] = {};    // [n-1][2][hL*wL]  planar
+    float* d_flow2[AVD_FB_LEVELS] = {};   // second flow buffer of a level: the fast level kernel (avd_fbfast.hip) ping-pongs
+    const float* flow_res[AVD_FB_LEVELS] = {};   // where the last call left the final flow of each level (d_flow or d_flow2)
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
@@ -150,6 +152,8 @@ struct avd_ctx {
     void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
     int cnn_tiles = 0;              // convolution tiling of the CNN extension: 0 = heuristic, 1 = 256-pixel tiles, 2 = 128 x 128 wherever possible
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
+    int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
+                                    // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
 };
 
 template <typename T>
@@ -201,3 +205,6 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
 // zero_first: the initial flow is zero whatever the buffer holds (the coarsest level: no clearing launch)
 int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first);
+// avd_fbfast.hip: ONE blur iteration of one pyramid level, a pair spread over several workgroups (column strips), the
+// horizontal window sums formed directly in double (the vertical chain stays literal); flow_in != flow_out
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int np, int zero_first);

@@ -34,15 +34,20 @@ res = {"label": label, "note": "mean per launch; FETCH_SIZE / WRITE_SIZE in KiB,
                                "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide); SQ_* cycle counters count quad-cycles",
        "kernels": kernels}
 # short names bench.py looks up
-for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_preprocess_vec", r"k_preprocess")):
+for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_fb_fast<320>", r"k_fb_fast<320"), ("k_preprocess_vec", r"k_preprocess_vec"),
+                   ("k_preprocess_nv12", r"k_preprocess_nv12")):
     for name, k in kernels.items():
         if re.search(pat, name) and "hbm_bytes" in k:
             res[short] = {"hbm_bytes": k["hbm_bytes"], "kernel": name}
-fb = [k for n, k in kernels.items() if re.search(r"k_fb_level|k_pyramid|k_polyexp|k_flow_up|k_stats|k_uv|k_hscan", n) and "hbm_bytes" in k]
+fb = [k for n, k in kernels.items() if re.search(r"k_fb_level|k_fb_fast|k_pyramid|k_polyexp|k_flow_up|k_stats|k_uv|k_hscan", n) and "hbm_bytes" in k]
 if fb:
     # per clip: launches per clip = launches / clips in the trace; every kernel above is launched a fixed number of times per clip
-    clips = min(k["launches"] for n, k in kernels.items() if re.search(r"k_fb_level<320", n)) or 1
+    # (the pyramid kernel exactly once)
+    clips = min([k["launches"] for n, k in kernels.items() if re.search(r"k_pyramid_all", n)] or [1]) or 1
     res["farneback_stage"] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for k in fb) / clips, "clips_in_trace": clips}
     res["whole_clip"] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for k in kernels.values() if "hbm_bytes" in k) / clips}
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
+for n, k in kernels.items():
+    if re.search(r"k_fb_fast|k_fb_level|k_polyexp|k_preprocess", n):
+        print(n, json.dumps({c: (round(v) if abs(v) > 100 else v) for c, v in k.items()}))
