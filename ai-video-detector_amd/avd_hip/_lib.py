@@ -23,7 +23,8 @@ SMALL, HASH = 320, 32
 EXPORTS = (
     "avd_abi_version", "avd_create", "avd_destroy", "avd_last_error",
     "avd_preprocess_bgr", "avd_farneback_pairs", "avd_analyze_frames",
-    "avd_analyze_frames_async", "avd_synchronize", "avd_wait_stream", "avd_release_workspace",
+    "avd_analyze_frames_async", "avd_synchronize", "avd_analyze_batch", "avd_analyze_batch_async",
+    "avd_wait_stream", "avd_release_workspace",
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
     "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features",
     "avd_cnn_param_counts", "avd_cnn_set_weights", "avd_cnn_forward", "avd_cnn_conv",
@@ -49,6 +50,12 @@ def f32_to_bf16_bits(a: np.ndarray) -> np.ndarray:
 
 def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
     return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+class AvdClip(C.Structure):
+    """struct avd_clip (include/avd.h): one clip of a batch, BGR (uv = NULL) or NV12."""
+    _fields_ = [("data", C.c_void_p), ("uv", C.c_void_p), ("mem", C.c_int), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int),
+                ("row_stride", C.c_int64), ("frame_stride", C.c_int64), ("uv_row_stride", C.c_int64), ("uv_frame_stride", C.c_int64)]
 
 
 class AvdError(RuntimeError):
@@ -124,6 +131,8 @@ def load() -> C.CDLL:
     L.avd_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.avd_allgather_records.argtypes = [vp, vp, C.c_int, vp]
     L.avd_synchronize.argtypes = [vp]
+    L.avd_analyze_batch.argtypes = [vp, vp, C.c_int, vp]
+    L.avd_analyze_batch_async.argtypes = [vp, vp, C.c_int, vp]
     L.avd_wait_stream.argtypes = [vp, vp]
     L.avd_release_workspace.argtypes = [vp]
     L.avd_timer_start.argtypes = [vp]
@@ -136,7 +145,7 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         if name not in ("avd_destroy", "avd_last_error", "avd_debug_fetch"):
             getattr(L, name).restype = C.c_int
-    if L.avd_abi_version() != 1:
+    if L.avd_abi_version() != 2:
         raise ImportError("libavd_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -414,6 +423,38 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.avd_synchronize(self._h))
+
+    # -- a batch of clips in one call (include/avd.h: avd_analyze_batch) -----------------------------------------
+    def _clip_array(self, clips):
+        """clips: sequence of BGR frame stacks uint8[N,H,W,3] or NV12 plane pairs (y, uv); numpy or torch, any mix of
+        geometries -> (AvdClip array, frame counts, keepalive)"""
+        arr = (AvdClip * len(clips))()
+        keep, counts = [], []
+        for i, c in enumerate(clips):
+            if isinstance(c, tuple):
+                yp, cp, mem, n, h, w, yr, cr, yf, cf, k = self._nv12_ptrs(*c)
+                arr[i] = AvdClip(yp, cp, mem, n, h, w, yr, yf, cr, cf)
+            else:
+                ptr, mem, n, h, w, rs, fs, k = self._frames_ptr(c)
+                arr[i] = AvdClip(ptr, None, mem, n, h, w, rs, fs, 0, 0)
+            keep.append(k)
+            counts.append(n)
+        return arr, counts, keep
+
+    def analyze_batch(self, clips):
+        """-> list of record arrays, one per clip (identical to analyze_frames / analyze_frames_nv12 per clip)."""
+        arr, counts, keep = self._clip_array(clips)
+        rec = np.zeros(sum(counts), RECORD_DTYPE)
+        self._check(self._L.avd_analyze_batch(self._h, arr, len(clips), rec.ctypes.data))
+        return list(np.split(rec, np.cumsum(counts)[:-1])) if counts else []
+
+    def analyze_batch_async(self, clips, rec: np.ndarray):
+        """Enqueue only; rec (RECORD_DTYPE, sum of the clips' frames) is filled by synchronize().  Returns what the caller
+        must keep alive until then."""
+        arr, counts, keep = self._clip_array(clips)
+        assert rec.dtype == RECORD_DTYPE and rec.size >= sum(counts) and rec.flags.c_contiguous
+        self._check(self._L.avd_analyze_batch_async(self._h, arr, len(clips), rec.ctypes.data))
+        return keep, counts
 
     def wait_stream(self, stream_handle: int = 0):
         """Order this context's stream behind everything already enqueued on another HIP stream (raw handle)."""

@@ -76,6 +76,8 @@ class ContextPool:
         for c in trim:                                     # outside the lock: this synchronises the context's stream
             try:
                 c.release_workspace()
+            except Exception:                              # must not mask the request's own result (or exception)
+                pass
             finally:
                 with self._cv:
                     self._cold.setdefault(device, []).append(c)
@@ -134,6 +136,22 @@ class FrameAnalyzer:
         rec = self.records(frames) if n else np.zeros(0, _lib.RECORD_DTYPE)
         return records_to_result(rec, h * w, meta.get("width") or w, meta.get("height") or h,
                                  meta.get("fps") or 0.0, meta.get("duration") or 0.0)
+
+    # -- several clips in one call (avd_analyze_batch): any mix of geometries; short clips fill the GPU together -------
+    def records_many(self, clips) -> list:
+        """clips: sequence of uint8[N,H,W,3] BGR stacks (or (y, uv) NV12 plane pairs) -> list of record arrays."""
+        return self.ctx.analyze_batch(list(clips))
+
+    def analyze_many(self, clips, metas) -> list:
+        """The batched form of ``analyze``: one result dict per clip, identical to analysing them one by one."""
+        clips = list(clips)
+        out = []
+        for frames, meta, rec in zip(clips, metas, self.records_many(clips)):
+            y = frames[0] if isinstance(frames, tuple) else frames
+            h, w = int(y.shape[1]), int(y.shape[2])
+            out.append(records_to_result(rec, h * w, meta.get("width") or w, meta.get("height") or h,
+                                         meta.get("fps") or 0.0, meta.get("duration") or 0.0))
+        return out
 
     # -- streaming: bounded host memory, one-frame halo between chunks ----------------------
     def records_stream(self, frames: Iterable[np.ndarray]) -> np.ndarray:
@@ -206,11 +224,26 @@ class ClipsInFlight:
         keep = self.ctxs[slot].analyze_frames_async(frames, rec)
         self._pending.append((slot, tag, rec, (frames, keep)))
 
+    def submit_batch(self, clips, tag=None) -> None:
+        """Enqueue SEVERAL clips as one call of one context (avd_analyze_batch_async): their Farneback pairs run as one
+        launch sequence.  drain() returns (tag, [records of clip 0, records of clip 1, ...])."""
+        if self.full:
+            raise RuntimeError("ClipsInFlight.submit_batch: all contexts busy, drain() first")
+        clips = list(clips)
+        slot = self._free.popleft()
+        total = sum(int((c[0] if isinstance(c, tuple) else c).shape[0]) for c in clips)
+        rec = np.zeros(total, _lib.RECORD_DTYPE)
+        keep, counts = self.ctxs[slot].analyze_batch_async(clips, rec)
+        self._pending.append((slot, tag, (rec, counts), (clips, keep)))
+
     def drain(self) -> Tuple[object, np.ndarray]:
-        """Wait for the OLDEST clip in flight -> (tag, records)."""
+        """Wait for the OLDEST clip (or batch) in flight -> (tag, records)."""
         slot, tag, rec, _frames = self._pending.popleft()
         self.ctxs[slot].synchronize()
         self._free.append(slot)
+        if isinstance(rec, tuple):
+            rec, counts = rec
+            return tag, (list(np.split(rec, np.cumsum(counts)[:-1])) if counts else [])
         return tag, rec
 
     def run(self, clips: Iterable[Tuple[object, object]]) -> Iterator[Tuple[object, np.ndarray]]:

@@ -8,7 +8,9 @@
 
 namespace {
 
-constexpr int kFbChunk = 128;      // Farneback pairs per workspace chunk (bounds HBM scratch)
+constexpr int kFbChunk = 128;      // Farneback pairs the scratch holds at first (one 120-frame clip)
+constexpr int kFbChunkMax = 512;   // ... and at most (2.6 GB): a batch of short clips runs as ONE launch sequence up to here;
+                                   // longer calls are processed in chunks of the reserved size with a one-frame overlap
 
 int rows_per_band_for(int w)
 {
@@ -44,7 +46,9 @@ void free_ws(Workspace& ws)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap); F(ws.d_lap_part);
-    F(ws.d_tables);
+    for (Geom& g : ws.geoms) F(g.d_tables);
+    F(ws.d_clipstart);
+    if (ws.h_clipstart) (void)hipHostFree(ws.h_clipstart);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); F(ws.d_flow2[k]); }
     F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
@@ -68,127 +72,196 @@ int check_geometry(avd_ctx* ctx, int n, int h, int w, int64_t row_stride, int64_
 }  // namespace
 
 // ---- workspace -----------------------------------------------------------------------
-int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
+// Build the tables of geometry (h, w) into cache entry g (its old table buffer is re-used when large enough).
+static int build_geom(avd_ctx* ctx, Geom& g, int h, int w)
+{
+    LinearTab lt;
+    AreaTab at;
+    build_linear_tab(h, w, AVD_SMALL, AVD_SMALL, lt);
+    int rc = build_area_tab(h, w, AVD_HASH, AVD_HASH, at);
+    if (rc) { ctx->err = "unsupported geometry for INTER_AREA"; return rc; }
+    const int R = rows_per_band_for(w);
+    const int nbands = (h + R - 1) / R;
+    std::vector<int> band_dy(nbands + 1, AVD_SMALL);
+    for (int b = 0; b <= nbands; b++) {
+        int d = 0;
+        while (d < AVD_SMALL && lt.y0[d] < b * R) d++;
+        band_dy[b] = d;
+    }
+    band_dy[nbands] = AVD_SMALL;
+    TableBlob tb;
+    std::vector<LinTap> lxt(AVD_SMALL), lyt(AVD_SMALL);
+    for (int d = 0; d < AVD_SMALL; d++) {
+        lxt[d] = LinTap{(short)lt.x0[d], (short)lt.x1[d], lt.a0[d], lt.a1[d]};
+        lyt[d] = LinTap{(short)lt.y0[d], (short)lt.y1[d], lt.b0[d], lt.b1[d]};
+    }
+    const size_t o_lxt = tb.push(lxt), o_lyt = tb.push(lyt);
+    const size_t o_band = tb.push(band_dy);
+    const size_t o_axb = tb.push(at.x.begin), o_axc = tb.push(at.x.count);
+    const size_t o_axf = tb.push(at.x.w_first), o_axm = tb.push(at.x.w_mid), o_axl = tb.push(at.x.w_last);
+    const size_t o_ayb = tb.push(at.y.begin), o_ayc = tb.push(at.y.count);
+    const size_t o_ayf = tb.push(at.y.w_first), o_aym = tb.push(at.y.w_mid), o_ayl = tb.push(at.y.w_last);
+    g.h = g.w = 0;                                     // not valid until everything below succeeded
+    uint8_t* dt = (uint8_t*)g.d_tables;
+    if (g.tables_bytes < tb.bytes.size()) {
+        // an evicted entry's tables may still be read by a kernel in flight on this context's stream: drain it first
+        // (only on the first use of a FIFTH distinct geometry, or of one with larger tables)
+        if (dt) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        g.tables_bytes = 0;
+        if (int e = dev_alloc(ctx, dt, tb.bytes.size())) { g.d_tables = nullptr; return e; }
+        g.d_tables = dt; g.tables_bytes = tb.bytes.size();
+    } else if (dt) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // re-using the buffer of an evicted geometry
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(dt, tb.bytes.data(), tb.bytes.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // tb goes out of scope
+    PreParams& P = g.pre;
+    P = PreParams{};
+    P.lxt = (const LinTap*)(dt + o_lxt); P.lyt = (const LinTap*)(dt + o_lyt);
+    P.band_dy = (const int*)(dt + o_band);
+    P.ax_begin = (const int*)(dt + o_axb); P.ax_count = (const int*)(dt + o_axc);
+    P.ax_first = (const float*)(dt + o_axf); P.ax_mid = (const float*)(dt + o_axm); P.ax_last = (const float*)(dt + o_axl);
+    P.area_fast = at.fast;
+    P.area_x_uniform4 = 1;
+    for (int d = 0; d < AVD_HASH; d++)
+        if ((at.x.begin[d] & 3) || (at.x.count[d] & 3) || at.x.count[d] < 4 || at.x.w_first[d] != at.x.w_mid[d] ||
+            at.x.w_last[d] != at.x.w_mid[d])
+            P.area_x_uniform4 = 0;
+    P.h = h; P.w = w; P.rows_per_band = R; P.nbands = nbands;
+    P.pitch = ((w + 32 + 15) / 16) * 16;
+    HashParams& H = g.hsh;
+    H = HashParams{};
+    H.ay_begin = (const int*)(dt + o_ayb); H.ay_count = (const int*)(dt + o_ayc);
+    H.ay_first = (const float*)(dt + o_ayf); H.ay_mid = (const float*)(dt + o_aym); H.ay_last = (const float*)(dt + o_ayl);
+    H.area_fast = at.fast;
+    H.fast_area = at.iscale_x * at.iscale_y;
+    H.fast_simd_w = (at.fast && at.iscale_x == 2 && at.iscale_y == 2) ? (AVD_HASH & ~7) : 0;
+    H.h = h;
+    g.h = h; g.w = w;
+    return 0;
+}
+
+// Make (h, w) the current geometry: ws.pre / ws.hsh are copies of its cache entry.  A hit costs nothing; a miss builds the
+// tables in a free entry, or in the least recently used one.
+int avd_ws_geometry(avd_ctx* ctx, int h, int w)
 {
     Workspace& ws = ctx->ws;
-    const bool geom_changed = ws.h != h || ws.w != w;
-    if (geom_changed) {
-        // a failure anywhere below must force a full rebuild on the next call (the tables and band layout of the NEW
-        // geometry are installed before the buffers are sized for it)
-        ws.h = ws.w = 0; ws.cap_n = 0;
-        LinearTab lt;
-        AreaTab at;
-        build_linear_tab(h, w, AVD_SMALL, AVD_SMALL, lt);
-        int rc = build_area_tab(h, w, AVD_HASH, AVD_HASH, at);
-        if (rc) { ctx->err = "unsupported geometry for INTER_AREA"; return rc; }
-        const int R = rows_per_band_for(w);
-        const int nbands = (h + R - 1) / R;
-        std::vector<int> band_dy(nbands + 1, AVD_SMALL);
-        for (int b = 0; b <= nbands; b++) {
-            int d = 0;
-            while (d < AVD_SMALL && lt.y0[d] < b * R) d++;
-            band_dy[b] = d;
-        }
-        band_dy[nbands] = AVD_SMALL;
-        TableBlob tb;
-        std::vector<LinTap> lxt(AVD_SMALL), lyt(AVD_SMALL);
-        for (int d = 0; d < AVD_SMALL; d++) {
-            lxt[d] = LinTap{(short)lt.x0[d], (short)lt.x1[d], lt.a0[d], lt.a1[d]};
-            lyt[d] = LinTap{(short)lt.y0[d], (short)lt.y1[d], lt.b0[d], lt.b1[d]};
-        }
-        const size_t o_lxt = tb.push(lxt), o_lyt = tb.push(lyt);
-        const size_t o_band = tb.push(band_dy);
-        const size_t o_axb = tb.push(at.x.begin), o_axc = tb.push(at.x.count);
-        const size_t o_axf = tb.push(at.x.w_first), o_axm = tb.push(at.x.w_mid), o_axl = tb.push(at.x.w_last);
-        const size_t o_ayb = tb.push(at.y.begin), o_ayc = tb.push(at.y.count);
-        const size_t o_ayf = tb.push(at.y.w_first), o_aym = tb.push(at.y.w_mid), o_ayl = tb.push(at.y.w_last);
-        uint8_t* dt = (uint8_t*)ws.d_tables;
-        if (int e = dev_alloc(ctx, dt, tb.bytes.size())) return e;
-        ws.d_tables = dt; ws.tables_bytes = tb.bytes.size();
-        HIP_TRY(ctx, hipMemcpyAsync(dt, tb.bytes.data(), tb.bytes.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // tb goes out of scope
-        PreParams& P = ws.pre;
-        P.lxt = (const LinTap*)(dt + o_lxt); P.lyt = (const LinTap*)(dt + o_lyt);
-        P.band_dy = (const int*)(dt + o_band);
-        P.ax_begin = (const int*)(dt + o_axb); P.ax_count = (const int*)(dt + o_axc);
-        P.ax_first = (const float*)(dt + o_axf); P.ax_mid = (const float*)(dt + o_axm); P.ax_last = (const float*)(dt + o_axl);
-        P.area_fast = at.fast;
-        P.area_x_uniform4 = 1;
-        for (int d = 0; d < AVD_HASH; d++)
-            if ((at.x.begin[d] & 3) || (at.x.count[d] & 3) || at.x.count[d] < 4 || at.x.w_first[d] != at.x.w_mid[d] ||
-                at.x.w_last[d] != at.x.w_mid[d])
-                P.area_x_uniform4 = 0;
-        P.h = h; P.w = w; P.rows_per_band = R; P.nbands = nbands;
-        P.pitch = ((w + 32 + 15) / 16) * 16;
-        HashParams& H = ws.hsh;
-        H.ay_begin = (const int*)(dt + o_ayb); H.ay_count = (const int*)(dt + o_ayc);
-        H.ay_first = (const float*)(dt + o_ayf); H.ay_mid = (const float*)(dt + o_aym); H.ay_last = (const float*)(dt + o_ayl);
-        H.area_fast = at.fast;
-        H.fast_area = at.iscale_x * at.iscale_y;
-        H.fast_simd_w = (at.fast && at.iscale_x == 2 && at.iscale_y == 2) ? (AVD_HASH & ~7) : 0;
-        H.h = h;
+    Geom* hit = nullptr;
+    Geom* victim = nullptr;                            // a free entry, else the least recently used one
+    for (Geom& g : ws.geoms) {
+        if (g.h == h && g.w == w) { hit = &g; break; }
+        if (!victim || (g.h == 0 && victim->h != 0) || (g.h != 0 && victim->h != 0 && g.stamp < victim->stamp)) victim = &g;
     }
-    if (geom_changed || n > ws.cap_n) {
+    if (!hit) {
+        ws.h = ws.w = 0;
+        if (int e = build_geom(ctx, *victim, h, w)) return e;
+        hit = victim;
+    }
+    hit->stamp = ++ws.geom_clock;
+    ws.pre = hit->pre; ws.hsh = hit->hsh;
+    ws.h = h; ws.w = w;
+    return 0;
+}
+
+// Per-frame buffers for n frames (all clips of a call), `rowbuf_elems` floats of INTER_AREA row partials and `lappart_elems`
+// long longs of Laplacian partial moments.  Grow-only: in steady state nothing is allocated or freed.
+int avd_ws_reserve_frames(avd_ctx* ctx, int n, size_t rowbuf_elems, size_t lappart_elems)
+{
+    Workspace& ws = ctx->ws;
+    if (n > ws.cap_n) {
         const int cap = std::max(n, 1);
         ws.cap_n = 0;                                  // not valid again until every buffer below exists
         if (int e = dev_alloc(ctx, ws.d_small, (size_t)cap * AVD_NPIX)) return e;
-        if (int e = dev_alloc(ctx, ws.d_rowbuf, (size_t)cap * h * AVD_HASH)) return e;
         if (int e = dev_alloc(ctx, ws.d_area, (size_t)cap * 1024)) return e;
         if (int e = dev_alloc(ctx, ws.d_hash, (size_t)cap * 1024)) return e;
         if (int e = dev_alloc(ctx, ws.d_ham, (size_t)cap)) return e;
         if (int e = dev_alloc(ctx, ws.d_lap, (size_t)cap * 2)) return e;
-        if (int e = dev_alloc(ctx, ws.d_lap_part, (size_t)cap * ws.pre.nbands * 8 * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_rec, (size_t)cap)) return e;
+        if (int e = dev_alloc(ctx, ws.d_clipstart, (size_t)cap)) return e;
         if (ws.h_rec) { (void)hipHostFree(ws.h_rec); ws.h_rec = nullptr; }
-        if (hipHostMalloc((void**)&ws.h_rec, sizeof(avd_frame_record) * cap, hipHostMallocDefault) != hipSuccess) {
+        if (ws.h_clipstart) { (void)hipHostFree(ws.h_clipstart); ws.h_clipstart = nullptr; }
+        if (hipHostMalloc((void**)&ws.h_rec, sizeof(avd_frame_record) * cap, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&ws.h_clipstart, sizeof(int) * cap, hipHostMallocDefault) != hipSuccess) {
             ctx->err = "hipHostMalloc failed"; return AVD_ERR_NOMEM;
         }
-        ws.cap_n = cap; ws.h = h; ws.w = w;
+        ws.cap_n = cap;
+    }
+    if (rowbuf_elems > ws.rowbuf_cap) {
+        ws.rowbuf_cap = 0;
+        if (int e = dev_alloc(ctx, ws.d_rowbuf, rowbuf_elems)) return e;
+        ws.rowbuf_cap = rowbuf_elems;
+    }
+    if (lappart_elems > ws.lappart_cap) {
+        ws.lappart_cap = 0;
+        if (int e = dev_alloc(ctx, ws.d_lap_part, lappart_elems)) return e;
+        ws.lappart_cap = lappart_elems;
     }
     return 0;
 }
 
-// Farneback scratch for up to kFbChunk pairs (kFbChunk+1 frames)
+static size_t rowbuf_elems_for(const Workspace& ws, int n) { return (size_t)n * ws.pre.h * AVD_HASH; }
+static size_t lappart_elems_for(const Workspace& ws, int n) { return (size_t)n * ws.pre.nbands * 8 * 2; }
+
+// one clip at offset 0 of the buffers
+int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
+{
+    if (int e = avd_ws_geometry(ctx, h, w)) return e;
+    Workspace& ws = ctx->ws;
+    ws.f0 = 0; ws.rowbuf_off = 0; ws.lappart_off = 0;
+    return avd_ws_reserve_frames(ctx, n, rowbuf_elems_for(ws, n), lappart_elems_for(ws, n));
+}
+
+// Farneback scratch for min(n - 1, kFbChunkMax) pairs, at least kFbChunk; grows when a call brings more pairs
 int avd_ws_reserve_fb(avd_ctx* ctx, int n)
 {
     Workspace& ws = ctx->ws;
-    const size_t nf = kFbChunk + 2, np = kFbChunk;       // +1 frame: the two segments of a chunk overlap by one frame
-    if (!ws.d_part) {                                    // d_part is allocated last: set = everything below exists
+    const int want = std::max(kFbChunk, std::min(std::max(n - 1, 0), kFbChunkMax));
+    if (want > ws.fb_cap) {
+        const size_t nf = (size_t)want + 2, np = (size_t)want;       // +1 frame: the two segments of a chunk overlap by one frame
+        ws.fb_cap = 0;
         for (int k = 0; k < AVD_FB_LEVELS; k++) {
             const size_t plane = (size_t)(AVD_SMALL >> k) * (AVD_SMALL >> k);
             if (int e = dev_alloc(ctx, ws.d_pyr[k], nf * plane)) return e;
             if (int e = dev_alloc(ctx, ws.d_poly[k], nf * 5 * plane)) return e;
             if (int e = dev_alloc(ctx, ws.d_flow[k], np * 2 * plane)) return e;
             if (int e = dev_alloc(ctx, ws.d_flow2[k], np * 2 * plane)) return e;
+            ws.flow_res[k] = nullptr;
         }
         if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_part, np * 2 * 16)) return e;
+        if (ws.d_vs) { (void)hipFree(ws.d_vs); ws.d_vs = nullptr; }
+        if (ws.d_vs0) { (void)hipFree(ws.d_vs0); ws.d_vs0 = nullptr; }
+        if (ws.d_flow_il) { (void)hipFree(ws.d_flow_il); ws.d_flow_il = nullptr; }
+        ws.fb_cap = want;
     }
-    // the double intermediate of the two-kernel fallback (525 MB): only when that path is selected
+    // the double intermediate of the two-kernel fallback (4 MB per pair): only when that path is selected
     const bool two_kernel = ctx->fb_mode == 0 && ctx->fb_fused != 0xF;
     if (two_kernel && !ws.d_vs) {
+        const size_t np = (size_t)ws.fb_cap;
         if (int e = dev_alloc(ctx, ws.d_vs0, np * 5 * AVD_SMALL * 8)) return e;
         if (int e = dev_alloc(ctx, ws.d_vs, np * (5 * AVD_NPIX + 512))) return e;      // + one pad tile per pair
     }
-    (void)n;
     return 0;
 }
 
 // ---- record assembly -------------------------------------------------------------------
+// clipstart[f] != 0: frame f is the first of its clip -- it has no predecessor (flow 0, like frame 0 of a single clip;
+// the pair (f - 1, f) the Farneback stage computed across the clip boundary is ignored)
 __global__ void k_records(const unsigned long long* lap, const int* ham, const float* stats, int stats_off,
-                          avd_frame_record* rec, int f0, int count, int write_pre, int write_flow)
+                          avd_frame_record* rec, int f0, int count, int write_pre, int write_flow, const int* clipstart)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int f = f0 + i;
+    const bool first = f == 0 || clipstart[f] != 0;
     if (write_pre) {
         rec[f].lap_sum = (int64_t)lap[2 * f];
         rec[f].lap_sumsq = (int64_t)lap[2 * f + 1];
         rec[f].ham = ham[f];
         rec[f].reserved = 0;
-        if (f == 0) { rec[f].flow_mean = 0.f; rec[f].flow_var = 0.f; }
+        if (first) { rec[f].flow_mean = 0.f; rec[f].flow_var = 0.f; }
     }
-    if (write_flow && f > 0) {
+    if (write_flow && !first) {
         rec[f].flow_mean = stats[2 * (f - 1 - stats_off)];
         rec[f].flow_var = stats[2 * (f - 1 - stats_off) + 1];
     }
@@ -201,13 +274,14 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
     Workspace& ws = ctx->ws;
     if (n < 2) return 0;
     if (int e = avd_ws_reserve_fb(ctx, n)) return e;
+    const int chunk = ws.fb_cap;
     if (h_flow_out && !ws.d_flow_il)
-        if (int e = dev_alloc(ctx, ws.d_flow_il, (size_t)kFbChunk * AVD_NPIX * 2)) return e;
+        if (int e = dev_alloc(ctx, ws.d_flow_il, (size_t)chunk * AVD_NPIX * 2)) return e;
     float* saved_il = ws.d_flow_il;
     if (!h_flow_out) ws.d_flow_il = nullptr;
     int rc = 0;
-    for (int p0 = 0; p0 < n - 1 && rc == 0; p0 += kFbChunk) {
-        const int np = std::min(kFbChunk, n - 1 - p0);
+    for (int p0 = 0; p0 < n - 1 && rc == 0; p0 += chunk) {
+        const int np = std::min(chunk, n - 1 - p0);
         const uint8_t* base = d_small + (size_t)p0 * AVD_NPIX;
         rc = launch_farneback(ctx, ctx->stream, base, np + 1, 0, 0);
         if (rc) break;
@@ -216,7 +290,7 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
         if (into_records) {
             hipLaunchKernelGGL(k_records, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
                                (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats,
-                               p0, ws.d_rec, p0 + 1, np, 0, 1);
+                               p0, ws.d_rec, p0 + 1, np, 0, 1, (const int*)ws.d_clipstart);
         }
         if (h_mean || h_var || h_flow_out) {
             std::vector<float> st((size_t)np * 2);
@@ -243,6 +317,7 @@ static int stage_input(avd_ctx* ctx, const uint8_t* src, int mem, size_t bytes, 
     if (mem != AVD_MEM_HOST) { ctx->err = "mem must be AVD_MEM_HOST or AVD_MEM_DEVICE"; return AVD_ERR_ARG; }
     Workspace& ws = ctx->ws;
     if (ws.stage_bytes < bytes) {
+        ws.stage_bytes = 0;                        // not valid again until the buffer exists
         if (int e = dev_alloc(ctx, ws.d_stage, bytes)) return e;
         ws.stage_bytes = bytes;
     }
@@ -351,56 +426,16 @@ static int impl_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, 
     if (int e = stage_input(ctx, small320, mem, (size_t)n * AVD_NPIX, &d_small)) return e;
     if (int e = run_flow_chunks(ctx, d_small, n, flow_mean, flow_var, flow_out, false)) return e;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->last_n = std::min(n, kFbChunk + 1);
+    ctx->last_n = std::min(n, ctx->ws.fb_cap + 1);
     return AVD_OK;
 }
 
-// Everything after the input-specific first stage: `first_stage` stages the input (if it lives on the host) and
-// enqueues the fused full-resolution kernel for its pixel format.
-template <typename F>
-static int analyze_async_common(avd_ctx* ctx, int n, int h, int w, avd_frame_record* records, F&& first_stage)
-{
-    if (n == 0) return AVD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->pending_out) { if (int e = impl_synchronize(ctx)) return e; }     // a previous call was never drained
-    if (int e = avd_ws_reserve(ctx, n, h, w)) return e;
-    if (int e = avd_ws_reserve_fb(ctx, n)) return e;
-    Workspace& ws = ctx->ws;
-    if (int e = first_stage()) return e;            // marks stages 0 / 1 around its kernel
-    if (int e = launch_hash(ctx, n)) return e;
-    hipLaunchKernelGGL(k_records, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats, 0,
-                       ws.d_rec, 0, n, 1, 0);
-    stage_mark(ctx, 2);
-    if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true)) return e;
-    stage_mark(ctx, 3);
-    // into PINNED memory: a device-to-host copy into the caller's pageable buffer would block this thread until
-    // the whole clip is done and the call would not be asynchronous at all; avd_synchronize hands the records over
-    HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->pending_out = records; ctx->pending_n = n;
-    stage_mark(ctx, 4);
-    ctx->last_n = n;
-    return AVD_OK;
-}
-
-static int impl_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
-                             int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
-{
-    if (!ctx) return AVD_ERR_ARG;
-    if ((!bgr || !records) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
-    if (int e = check_geometry(ctx, n, h, w, row_stride, frame_stride)) return e;
-    return analyze_async_common(ctx, n, h, w, records, [&]() -> int {
-        const uint8_t* d_bgr = nullptr;
-        const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;
-        if (int e = stage_input(ctx, bgr, mem, bytes, &d_bgr)) return e;
-        stage_mark(ctx, 0);
-        if (int e = launch_preprocess(ctx, d_bgr, n, h, w, row_stride, frame_stride)) return e;
-        stage_mark(ctx, 1);
-        return 0;
-    });
-}
-
-// ---- NV12 input (decoder surfaces) -------------------------------------------------------------------------
+// ---- the whole per-frame path for a BATCH of clips ------------------------------------------------------------------------
+// Frames of all clips are concatenated in the per-frame buffers (small320, hashes, moments, records): clip c occupies frames
+// [f0_c, f0_c + n_c).  Preprocess / hash / Hamming run per clip with that clip's geometry (cached tables); the Farneback
+// stage does not care where a 320 x 320 frame came from: it runs ONCE over all N - 1 consecutive pairs of the concatenation
+// (the one pair per clip boundary it computes in vain is ignored by k_records), so K short clips cost one launch sequence
+// over all their pairs instead of K sequences that each leave most of the chip idle.
 struct Nv12Arg {
     const uint8_t *y, *uv;
     int64_t y_row, uv_row, y_frame, uv_frame;
@@ -418,6 +453,142 @@ static int check_nv12(avd_ctx* ctx, const Nv12Arg& a, int n, int h, int w)
     return 0;
 }
 
+static size_t clip_stage_bytes(const avd_clip& c, size_t* chroma_off)
+{
+    if (c.mem != AVD_MEM_HOST || c.n <= 0) { if (chroma_off) *chroma_off = 0; return 0; }
+    if (!c.uv) {
+        if (chroma_off) *chroma_off = 0;
+        return ((size_t)c.frame_stride * (c.n - 1) + (size_t)c.row_stride * (c.h - 1) + (size_t)c.w * 3 + 255) / 256 * 256;
+    }
+    const size_t ybytes = (size_t)c.frame_stride * (c.n - 1) + (size_t)c.row_stride * (c.h - 1) + (size_t)c.w;
+    const size_t cbytes = (size_t)c.uv_frame_stride * (c.n - 1) + (size_t)c.uv_row_stride * (c.h / 2 - 1) + (size_t)c.w;
+    const size_t coff = (ybytes + 255) / 256 * 256;
+    if (chroma_off) *chroma_off = coff;
+    return (coff + cbytes + 255) / 256 * 256;
+}
+
+static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int nclips, avd_frame_record* records)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (nclips < 0 || (nclips > 0 && !clips)) { ctx->err = "bad clip list"; return AVD_ERR_ARG; }
+    int64_t total = 0;
+    for (int c = 0; c < nclips; c++) {
+        const avd_clip& k = clips[c];
+        if (k.mem != AVD_MEM_HOST && k.mem != AVD_MEM_DEVICE) { ctx->err = "mem must be AVD_MEM_HOST or AVD_MEM_DEVICE"; return AVD_ERR_ARG; }
+        if (!k.data && k.n > 0) { ctx->err = "null frame pointer"; return AVD_ERR_ARG; }
+        if (k.uv) {
+            const Nv12Arg a{k.data, k.uv, k.row_stride, k.uv_row_stride, k.frame_stride, k.uv_frame_stride};
+            if (int e = check_nv12(ctx, a, k.n, k.h, k.w)) return e;
+        } else if (int e = check_geometry(ctx, k.n, k.h, k.w, k.row_stride, k.frame_stride)) return e;
+        total += k.n;
+    }
+    if (total > (1 << 24)) { ctx->err = "too many frames in one call"; return AVD_ERR_ARG; }
+    if (total == 0) return AVD_OK;
+    if (!records) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    const int n = (int)total;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending_out) { if (int e = impl_synchronize(ctx)) return e; }     // a previous call was never drained
+    Workspace& ws = ctx->ws;
+    // pass 1: geometry tables (cached) and sizes -- everything is reserved before the first launch of the call
+    size_t rowbuf_elems = 0, lappart_elems = 0, stage_bytes = 0;
+    for (int c = 0; c < nclips; c++) {
+        const avd_clip& k = clips[c];
+        if (k.n == 0) continue;
+        if (int e = avd_ws_geometry(ctx, k.h, k.w)) return e;
+        rowbuf_elems += rowbuf_elems_for(ws, k.n);
+        lappart_elems += lappart_elems_for(ws, k.n);
+        stage_bytes += clip_stage_bytes(k, nullptr);
+    }
+    if (int e = avd_ws_reserve_frames(ctx, n, rowbuf_elems, lappart_elems)) return e;
+    if (int e = avd_ws_reserve_fb(ctx, n)) return e;
+    if (ws.stage_bytes < stage_bytes) {
+        ws.stage_bytes = 0;
+        if (int e = dev_alloc(ctx, ws.d_stage, stage_bytes)) return e;
+        ws.stage_bytes = stage_bytes;
+    }
+    // pass 2: per clip, stage (host input) -> fused full-resolution kernel -> hash / Hamming, at the clip's offsets
+    stage_mark(ctx, 0);
+    int f0 = 0;
+    size_t rb = 0, lp = 0, st = 0;
+    for (int c = 0; c < nclips; c++) {
+        const avd_clip& k = clips[c];
+        if (k.n == 0) continue;
+        if (int e = avd_ws_geometry(ctx, k.h, k.w)) return e;       // a cache hit (pass 1 built it) unless > kGeomCache geometries
+        ws.f0 = f0; ws.rowbuf_off = rb; ws.lappart_off = lp;
+        ws.h_clipstart[f0] = 1;
+        for (int i = 1; i < k.n; i++) ws.h_clipstart[f0 + i] = 0;
+        size_t coff = 0;
+        const size_t sb = clip_stage_bytes(k, &coff);
+        const uint8_t* d_in = k.data;
+        const uint8_t* d_uv = k.uv;
+        if (k.mem == AVD_MEM_HOST) {
+            uint8_t* dst = ws.d_stage + st;
+            if (!k.uv) {
+                const size_t bytes = (size_t)k.frame_stride * (k.n - 1) + (size_t)k.row_stride * (k.h - 1) + (size_t)k.w * 3;
+                HIP_TRY(ctx, hipMemcpyAsync(dst, k.data, bytes, hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                const size_t ybytes = (size_t)k.frame_stride * (k.n - 1) + (size_t)k.row_stride * (k.h - 1) + (size_t)k.w;
+                const size_t cbytes = (size_t)k.uv_frame_stride * (k.n - 1) + (size_t)k.uv_row_stride * (k.h / 2 - 1) + (size_t)k.w;
+                HIP_TRY(ctx, hipMemcpyAsync(dst, k.data, ybytes, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(dst + coff, k.uv, cbytes, hipMemcpyHostToDevice, ctx->stream));
+                d_uv = dst + coff;
+            }
+            d_in = dst;
+            st += sb;
+        }
+        if (!k.uv) {
+            if (int e = launch_preprocess(ctx, d_in, k.n, k.h, k.w, k.row_stride, k.frame_stride)) return e;
+        } else {
+            Nv12Params nv{};
+            nv.uv = d_uv; nv.uv_row_stride = k.uv_row_stride; nv.uv_frame_stride = k.uv_frame_stride;
+            build_yuv_consts(nv.k);
+            if (int e = launch_preprocess_nv12(ctx, d_in, nv, k.n, k.h, k.w, k.row_stride, k.frame_stride)) return e;
+        }
+        if (int e = launch_hash(ctx, k.n)) return e;
+        f0 += k.n;
+        rb += rowbuf_elems_for(ws, k.n);
+        lp += lappart_elems_for(ws, k.n);
+    }
+    ws.f0 = 0; ws.rowbuf_off = 0; ws.lappart_off = 0;
+    stage_mark(ctx, 1);
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_clipstart, ws.h_clipstart, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_records, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats, 0,
+                       ws.d_rec, 0, n, 1, 0, (const int*)ws.d_clipstart);
+    stage_mark(ctx, 2);
+    if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true)) return e;
+    stage_mark(ctx, 3);
+    // into PINNED memory: a device-to-host copy into the caller's pageable buffer would block this thread until
+    // the whole call is done and it would not be asynchronous at all; avd_synchronize hands the records over
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending_out = records; ctx->pending_n = n;
+    stage_mark(ctx, 4);
+    ctx->last_n = n;
+    return AVD_OK;
+}
+
+static int impl_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int w,
+                             int64_t row_stride, int64_t frame_stride, avd_frame_record* records)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if ((!bgr || !records) && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    avd_clip k{};
+    k.data = bgr; k.uv = nullptr; k.mem = mem; k.n = n; k.h = h; k.w = w;
+    k.row_stride = row_stride; k.frame_stride = frame_stride;
+    return impl_analyze_batch_async(ctx, &k, 1, records);
+}
+
+static int impl_analyze_frames_nv12_async(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w, avd_frame_record* records)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (!records && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
+    if (int e = check_nv12(ctx, a, n, h, w)) return e;
+    avd_clip k{};
+    k.data = a.y; k.uv = a.uv; k.mem = mem; k.n = n; k.h = h; k.w = w;
+    k.row_stride = a.y_row; k.frame_stride = a.y_frame; k.uv_row_stride = a.uv_row; k.uv_frame_stride = a.uv_frame;
+    return impl_analyze_batch_async(ctx, &k, 1, records);
+}
+
 // host planes are staged back to back (the chroma plane on a 256-byte boundary); device planes are used in place
 static int stage_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w, const uint8_t** d_y, Nv12Params* nv)
 {
@@ -430,6 +601,7 @@ static int stage_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int
     const size_t coff = (ybytes + 255) / 256 * 256;
     Workspace& ws = ctx->ws;
     if (ws.stage_bytes < coff + cbytes) {
+        ws.stage_bytes = 0;
         if (int e = dev_alloc(ctx, ws.d_stage, coff + cbytes)) return e;
         ws.stage_bytes = coff + cbytes;
     }
@@ -437,22 +609,6 @@ static int stage_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int
     HIP_TRY(ctx, hipMemcpyAsync(ws.d_stage + coff, a.uv, cbytes, hipMemcpyHostToDevice, ctx->stream));
     *d_y = ws.d_stage; nv->uv = ws.d_stage + coff;
     return 0;
-}
-
-static int impl_analyze_frames_nv12_async(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w, avd_frame_record* records)
-{
-    if (!ctx) return AVD_ERR_ARG;
-    if (!records && n > 0) { ctx->err = "null pointer"; return AVD_ERR_ARG; }
-    if (int e = check_nv12(ctx, a, n, h, w)) return e;
-    return analyze_async_common(ctx, n, h, w, records, [&]() -> int {
-        const uint8_t* d_y = nullptr;
-        Nv12Params nv{};
-        if (int e = stage_nv12(ctx, a, mem, n, h, w, &d_y, &nv)) return e;
-        stage_mark(ctx, 0);
-        if (int e = launch_preprocess_nv12(ctx, d_y, nv, n, h, w, a.y_row, a.y_frame)) return e;
-        stage_mark(ctx, 1);
-        return 0;
-    });
 }
 
 static int impl_preprocess_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, int h, int w,
@@ -563,10 +719,10 @@ static int64_t impl_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_
     if (std::strcmp(name, "area") == 0) { src = ws.d_area; bytes = (size_t)n * 1024; }
     else if (std::strcmp(name, "small") == 0) { src = ws.d_small; bytes = (size_t)n * AVD_NPIX; }
     // the Farneback scratch holds ONE chunk (kFbChunk pairs): for longer clips these are the last chunk's buffers
-    else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)std::min(n, kFbChunk + 1) * (AVD_NPIX >> (2 * k)) * 4; }
-    else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)std::min(n, kFbChunk + 1) * 5 * (AVD_NPIX >> (2 * k)) * 4; }
-    else if ((k = level("flow")) >= 0) { src = ws.flow_res[k] ? ws.flow_res[k] : ws.d_flow[k]; bytes = (size_t)std::min(std::max(n - 1, 0), kFbChunk) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
-    else if (std::strcmp(name, "vs0") == 0) { src = ws.d_vs0; bytes = (size_t)kFbChunk * 5 * AVD_SMALL * 8 * 8; }
+    else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)std::min(n, ws.fb_cap + 1) * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)std::min(n, ws.fb_cap + 1) * 5 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if ((k = level("flow")) >= 0) { src = ws.flow_res[k] ? ws.flow_res[k] : ws.d_flow[k]; bytes = (size_t)std::min(std::max(n - 1, 0), ws.fb_cap) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
+    else if (std::strcmp(name, "vs0") == 0) { src = ws.d_vs0; bytes = (size_t)ws.fb_cap * 5 * AVD_SMALL * 8 * 8; }
     else { ctx->err = "unknown debug buffer"; return AVD_ERR_ARG; }
     if (!src) { ctx->err = "buffer not allocated yet"; return AVD_ERR_ARG; }
     bytes = std::min(bytes, out_bytes);
@@ -799,6 +955,19 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
 }
 
 int avd_synchronize(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_synchronize(ctx); }); }
+
+int avd_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int nclips, avd_frame_record* records)
+{
+    return guarded(ctx, [&] { return impl_analyze_batch_async(ctx, clips, nclips, records); });
+}
+
+int avd_analyze_batch(avd_ctx* ctx, const avd_clip* clips, int nclips, avd_frame_record* records)
+{
+    return guarded(ctx, [&] {
+        const int rc = impl_analyze_batch_async(ctx, clips, nclips, records);
+        return rc ? rc : impl_synchronize(ctx);
+    });
+}
 
 int avd_preprocess_nv12(avd_ctx* ctx, const uint8_t* y, const uint8_t* uv, int mem, int n, int h, int w, int64_t y_row_stride,
                         int64_t uv_row_stride, int64_t y_frame_stride, int64_t uv_frame_stride, uint8_t* small320,

@@ -84,9 +84,28 @@ struct HashParams {
     int h;
 };
 
+// Tables and band layout of one frame geometry.  A context keeps the last kGeomCache geometries (a mixed-resolution
+// stream alternates between a few sizes): switching between cached geometries allocates and frees nothing.
+constexpr int kGeomCache = 4;
+struct Geom {
+    int h = 0, w = 0;
+    void* d_tables = nullptr; size_t tables_bytes = 0;
+    PreParams pre{};
+    HashParams hsh{};
+    unsigned long long stamp = 0;      // last use (LRU eviction)
+};
+
 struct Workspace {
-    // geometry the workspace was sized for
+    // geometry of the clip being enqueued (a copy of its cache entry) and the capacities of the per-frame buffers, which
+    // only ever grow: cap_n frames, rowbuf_cap floats, lappart_cap slots
     int cap_n = 0, h = 0, w = 0;
+    size_t rowbuf_cap = 0, lappart_cap = 0;
+    Geom geoms[kGeomCache];
+    unsigned long long geom_clock = 0;
+    // position of the clip being enqueued inside the buffers of the call (a batch concatenates its clips)
+    int f0 = 0; size_t rowbuf_off = 0, lappart_off = 0;
+    int fb_cap = 0;                    // pairs the Farneback scratch holds
+    int* d_clipstart = nullptr; int* h_clipstart = nullptr; int clipstart_cap = 0;   // [n] 1 = first frame of a clip
     // preprocess
     uint8_t* d_stage = nullptr; size_t stage_bytes = 0;   // staged host frames
     uint8_t* d_small = nullptr;       // [n][320*320]
@@ -97,7 +116,6 @@ struct Workspace {
     unsigned long long* d_lap = nullptr;   // [n][2]
     long long* d_lap_part = nullptr;       // [n][nbands][8 waves][2] per-wave partial moments
     int lap_waves = 4;
-    void* d_tables = nullptr; size_t tables_bytes = 0;
     PreParams pre{};
     HashParams hsh{};
     // farneback
@@ -171,7 +189,9 @@ inline int dev_alloc(avd_ctx* ctx, T*& p, size_t count)
 }
 
 // ---- stage launchers (each enqueues on ctx->stream) --------------------------------
-int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w);
+int avd_ws_geometry(avd_ctx* ctx, int h, int w);                       // make (h, w) the current geometry (cached tables)
+int avd_ws_reserve_frames(avd_ctx* ctx, int n, size_t rowbuf_elems, size_t lappart_elems);   // grow-only per-frame buffers
+int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w);                 // both, for one clip at offset 0
 int avd_ws_reserve_fb(avd_ctx* ctx, int n);
 int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
                       int64_t row_stride, int64_t frame_stride);

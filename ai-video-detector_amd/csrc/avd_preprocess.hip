@@ -717,10 +717,10 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
     do {                                                                                                             \
         if (nt == 512)                                                                                               \
             hipLaunchKernelGGL((k_preprocess_vec<N, 512>), dim3(grid1), dim3(512), lds_vec, ctx->stream, d_bgr, n, P, \
-                               ws.d_small, ws.d_rowbuf, ws.d_lap_part);                                              \
+                               ws.d_small + (size_t)ws.f0 * AVD_NPIX, ws.d_rowbuf + ws.rowbuf_off, ws.d_lap_part + ws.lappart_off);                                              \
         else                                                                                                         \
             hipLaunchKernelGGL((k_preprocess_vec<N, 256>), dim3(grid1), dim3(256), lds_vec, ctx->stream, d_bgr, n, P, \
-                               ws.d_small, ws.d_rowbuf, ws.d_lap_part);                                              \
+                               ws.d_small + (size_t)ws.f0 * AVD_NPIX, ws.d_rowbuf + ws.rowbuf_off, ws.d_lap_part + ws.lappart_off);                                              \
     } while (0)
         switch (ni_nt) {
         case 1: case 2: case 3: AVD_VEC_CASE(3); break;
@@ -737,10 +737,10 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
         const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
         if (vec)
             hipLaunchKernelGGL(k_preprocess<true>, dim3(grid), dim3(kThreads), lds, ctx->stream,
-                               d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part);
+                               d_bgr, n, P, ws.d_small + (size_t)ws.f0 * AVD_NPIX, ws.d_rowbuf + ws.rowbuf_off, ws.d_lap_part + ws.lappart_off);
         else
             hipLaunchKernelGGL(k_preprocess<false>, dim3(grid), dim3(kThreads), lds, ctx->stream,
-                               d_bgr, n, P, ws.d_small, ws.d_rowbuf, ws.d_lap_part);
+                               d_bgr, n, P, ws.d_small + (size_t)ws.f0 * AVD_NPIX, ws.d_rowbuf + ws.rowbuf_off, ws.d_lap_part + ws.lappart_off);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -764,11 +764,11 @@ int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& n
     // conversion's integer arithmetic, not by how its loads are issued -- profiles/r02_experiments.md)
     ws.lap_waves = kThreads / 64;
     if (vec)
-        hipLaunchKernelGGL(k_preprocess_nv12<true>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small,
-                           ws.d_rowbuf, ws.d_lap_part);
+        hipLaunchKernelGGL(k_preprocess_nv12<true>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small + (size_t)ws.f0 * AVD_NPIX,
+                           ws.d_rowbuf + ws.rowbuf_off, ws.d_lap_part + ws.lappart_off);
     else
-        hipLaunchKernelGGL(k_preprocess_nv12<false>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small,
-                           ws.d_rowbuf, ws.d_lap_part);
+        hipLaunchKernelGGL(k_preprocess_nv12<false>, dim3(grid), dim3(kThreads), lds, ctx->stream, d_y, nv, n, P, ws.d_small + (size_t)ws.f0 * AVD_NPIX,
+                           ws.d_rowbuf + ws.rowbuf_off, ws.d_lap_part + ws.lappart_off);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -776,9 +776,12 @@ int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& n
 int launch_hash(avd_ctx* ctx, int n)
 {
     Workspace& ws = ctx->ws;
-    hipLaunchKernelGGL(k_hash, dim3(n), dim3(1024), 0, ctx->stream, ws.d_rowbuf, ws.hsh, ws.d_area, ws.d_hash,
-                       (const long long*)ws.d_lap_part, ws.pre.nbands, ws.lap_waves, ws.d_lap);
-    hipLaunchKernelGGL(k_hamming, dim3(n), dim3(256), 0, ctx->stream, ws.d_hash, ws.d_ham);
+    // the clip's slice of the call's buffers: frame ws.f0 onwards (the first frame of a clip has no predecessor: ham = -1)
+    const size_t f0 = (size_t)ws.f0;
+    hipLaunchKernelGGL(k_hash, dim3(n), dim3(1024), 0, ctx->stream, ws.d_rowbuf + ws.rowbuf_off, ws.hsh, ws.d_area + f0 * 1024,
+                       ws.d_hash + f0 * 1024, (const long long*)(ws.d_lap_part + ws.lappart_off), ws.pre.nbands, ws.lap_waves,
+                       ws.d_lap + 2 * f0);
+    hipLaunchKernelGGL(k_hamming, dim3(n), dim3(256), 0, ctx->stream, ws.d_hash + f0 * 1024, ws.d_ham + f0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -46,7 +46,7 @@ enum avd_mem { AVD_MEM_HOST = 0, AVD_MEM_DEVICE = 1 };
 
 #define AVD_SMALL 320          /* video.py:43 resize target */
 #define AVD_HASH 32            /* video.py:36 aHash size */
-#define AVD_ABI_VERSION 1
+#define AVD_ABI_VERSION 2
 
 /* One record per sampled frame: everything video.py:36-57 derives from pixels.
  * The scalar tail (tex variance, ai_susp, summary, timeline; video.py:54-83) is
@@ -104,6 +104,25 @@ int avd_analyze_frames_async(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, i
                              int64_t row_stride, int64_t frame_stride,
                              avd_frame_record* records);
 int avd_synchronize(avd_ctx* ctx);
+
+/* A BATCH of clips in one call (BASELINE.json configs[2] / configs[4]: many concurrent clips, mixed resolutions).  The
+ * reference analyses one file per request in a sequential loop (app/analyzers/video.py:27-58); a service that has several
+ * short clips waiting hands them over together: preprocess / hash / Hamming run per clip with that clip's geometry (the
+ * tables of the last few geometries are cached per context: no allocation in steady state), then ONE Farneback launch
+ * sequence covers the pairs of all clips (that stage is 320 x 320 whatever the source resolution), so thirteen 20-frame
+ * clips fill the chip like one long clip instead of running thirteen sequences of 19 pairs each.
+ * A clip is BGR (uv == NULL: data = frames, row_stride / frame_stride in bytes) or NV12 (data = Y plane, uv = interleaved
+ * chroma plane, the four strides as for avd_analyze_frames_nv12).  records: host, sum of clips[i].n entries, clip after
+ * clip; the first record of every clip has ham = -1 and flow 0 (video.py:37-41, 55).  Results are identical to calling
+ * avd_analyze_frames per clip. */
+typedef struct avd_clip {
+    const uint8_t* data;
+    const uint8_t* uv;
+    int mem, n, h, w;
+    int64_t row_stride, frame_stride, uv_row_stride, uv_frame_stride;
+} avd_clip;
+int avd_analyze_batch(avd_ctx* ctx, const avd_clip* clips, int nclips, avd_frame_record* records);
+int avd_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int nclips, avd_frame_record* records);
 
 /* NV12 input (decode -> ingest).  Hardware decoders (VCN / rocDecode) and most software decoders
  * produce YUV 4:2:0, not BGR; the reference gets BGR because cv2.VideoCapture.retrieve() runs libswscale on the
@@ -215,7 +234,13 @@ int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
  * by AVD_FB_FUSED: mean duration of one k_uv launch), 5 = mean duration of one k_hscan<320> launch (two-kernel path only,
  * otherwise 0). */
 int avd_set_profiling(avd_ctx* ctx, int enable);
-/* Tuning / test switches (no effect on results).  "fb_fused": bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
+/* Tuning / test switches.  "fb_mode": 1 (default; environment AVD_FB_MODE=fast) = the fast Farneback level kernel
+ * (csrc/avd_fbfast.hip: a pair is spread over several workgroups; cv2's vertical running sums are kept literally, the
+ * horizontal 15-column window sums are formed directly in double instead of as cv2's running double sum: the flow equals
+ * the exact kernels' bit for bit on well-posed inputs and stays within 1e-5 px / ai_susp within 1e-6 otherwise, except on
+ * chaotic pairs where the reference result itself moves by more under a 1-ulp perturbation, tests/test_gpu_fbfast.py);
+ * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
+ * "fb_fused" (exact mode only, no effect on results): bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
  * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
  * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM.  "cnn_tiles": tiling of the
  * CNN extension's convolutions, 0 = by layer shape (default), 1 = 256-pixel tiles everywhere, 2 = 128 x 128 tiles wherever the
