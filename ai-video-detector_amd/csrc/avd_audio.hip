@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void k_audio_prepare(const float* __restrict__
 // ---- pass 2: |rfft| + 1e-9 by direct evaluation -----------------------------------------------------------------
 // grid (windows, ceil(max_bins / 256)); LDS: window [L] + cosine table [L] (dynamic, 16 * L bytes)
 __global__ __launch_bounds__(256) void k_audio_dft(const double* __restrict__ xw, int64_t n, int win,
-                                                  const double* __restrict__ cos_full, const double* __restrict__ cos_last,
-                                                  const double* __restrict__ sin_last, double* __restrict__ mag, int first_window)
+                                                  const double* __restrict__ cos_full, const double* __restrict__ sin_full,
+                                                  const double* __restrict__ cos_last, const double* __restrict__ sin_last,
+                                                  double* __restrict__ mag, int first_window)
 {
     extern __shared__ __align__(16) double lds[];
     const int wdx = first_window + blockIdx.x, tid = threadIdx.x;   // the windows before first_window went through the FFT path
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void k_audio_dft(const double* __restrict__ xw
             js += k; if (js >= L) js -= L;
         }
     } else {
-        const double* st = sin_last;                        // the (short) last window of a stream: sines from global memory
+        // a length that is not a multiple of 4 has no quarter period in its cosine table: sines of THIS length from
+        // global memory (full windows of a caller-chosen size as well as the short last window of a stream)
+        const double* st = full ? sin_full : sin_last;
         int j = 0;
         for (int i = 0; i < L; i++) {
             const double v = x[i];
@@ -223,25 +226,28 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
     const int last = (int)(n - (int64_t)(nwin - 1) * win);
     if (ws.audio_win != win || ws.audio_last != last) {
         // tables: np.hanning of both window lengths, cos(2 pi j / L) (and sin for the last length)
-        std::vector<double> hf(win), hl(last), cf(win), cl(last), sl(last);
+        std::vector<double> hf(win), hl(last), cf(win), sf(win), cl(last), sl(last);
         // np.hanning(M) = 0.5 + 0.5 cos(pi n / (M-1)) for n = 1-M, 3-M, ..., M-1 (ones for M = 1)
         for (int i = 0; i < win; i++) hf[i] = win == 1 ? 1.0 : 0.5 + 0.5 * std::cos(M_PI * (double)(2 * i + 1 - win) / (double)(win - 1));
         for (int i = 0; i < last; i++) hl[i] = last == 1 ? 1.0 : 0.5 + 0.5 * std::cos(M_PI * (double)(2 * i + 1 - last) / (double)(last - 1));
-        for (int j = 0; j < win; j++) cf[j] = std::cos(2.0 * M_PI * (double)j / (double)win);
+        for (int j = 0; j < win; j++) { cf[j] = std::cos(2.0 * M_PI * (double)j / (double)win); sf[j] = std::sin(2.0 * M_PI * (double)j / (double)win); }
         for (int j = 0; j < last; j++) { cl[j] = std::cos(2.0 * M_PI * (double)j / (double)last); sl[j] = std::sin(2.0 * M_PI * (double)j / (double)last); }
-        const size_t need = (size_t)2 * win + 3 * (size_t)last;
+        const size_t need = (size_t)3 * win + 3 * (size_t)last;
+        ws.audio_win = ws.audio_last = 0;                     // the tables are not valid again until every copy below is enqueued
         if (ws.audio_tab_elems < need) {
             if (ws.d_audio_tab) (void)hipFree(ws.d_audio_tab);
             ws.d_audio_tab = nullptr;
+            ws.audio_tab_elems = 0;
             if (hipMalloc((void**)&ws.d_audio_tab, need * sizeof(double)) != hipSuccess) { ctx->err = "hipMalloc (audio tables)"; return AVD_ERR_NOMEM; }
             ws.audio_tab_elems = need;
         }
         double* t = ws.d_audio_tab;
         HIP_TRY(ctx, hipMemcpyAsync(t, hf.data(), sizeof(double) * win, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(t + win, cf.data(), sizeof(double) * win, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(t + 2 * win, hl.data(), sizeof(double) * last, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(t + 2 * win + last, cl.data(), sizeof(double) * last, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(t + 2 * win + 2 * last, sl.data(), sizeof(double) * last, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(t + 2 * win, sf.data(), sizeof(double) * win, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(t + 3 * win, hl.data(), sizeof(double) * last, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(t + 3 * win + last, cl.data(), sizeof(double) * last, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(t + 3 * win + 2 * last, sl.data(), sizeof(double) * last, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope
         ws.audio_win = win; ws.audio_last = last;
     }
@@ -253,6 +259,7 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
     if (ws.audio_buf_elems < xw_need + mag_need + b_need) {
         if (ws.d_audio_buf) (void)hipFree(ws.d_audio_buf);
         ws.d_audio_buf = nullptr;
+        ws.audio_buf_elems = 0;
         if (hipMalloc((void**)&ws.d_audio_buf, (xw_need + mag_need + b_need) * sizeof(double)) != hipSuccess) { ctx->err = "hipMalloc (audio scratch)"; return AVD_ERR_NOMEM; }
         ws.audio_buf_elems = xw_need + mag_need + b_need;
     }
@@ -260,7 +267,7 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
     double *xw = ws.d_audio_buf, *mag = ws.d_audio_buf + xw_need;
     double2* bbuf = reinterpret_cast<double2*>(ws.d_audio_buf + xw_need + mag_need);
     hipLaunchKernelGGL(k_audio_prepare, dim3(nwin), dim3(256), 0, ctx->stream, d_wav, n, win, (const double*)t,
-                       (const double*)(t + 2 * win), xw, d_out);
+                       (const double*)(t + 3 * win), xw, d_out);
     // per call (a function attribute belongs to the current device; a process may hold contexts on several)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_audio_fft_a, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * kFftN));
@@ -272,7 +279,8 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
     if (nfull < nwin) {
         const size_t lds = (size_t)16 * win;
         hipLaunchKernelGGL(k_audio_dft, dim3(nwin - nfull, (win / 2 + 1 + 255) / 256), dim3(256), lds, ctx->stream, (const double*)xw, n, win,
-                           (const double*)(t + win), (const double*)(t + 2 * win + last), (const double*)(t + 2 * win + 2 * last), mag, nfull);
+                           (const double*)(t + win), (const double*)(t + 2 * win), (const double*)(t + 3 * win + last),
+                           (const double*)(t + 3 * win + 2 * last), mag, nfull);
     }
     hipLaunchKernelGGL(k_audio_reduce, dim3(nwin), dim3(256), 0, ctx->stream, (const double*)mag, win, d_out);
     HIP_TRY(ctx, hipGetLastError());

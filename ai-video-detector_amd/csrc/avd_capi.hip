@@ -42,9 +42,17 @@ struct TableBlob {
     }
 };
 
-void free_ws(Workspace& ws)
+// keep_weights: avd_release_workspace gives SCRATCH back; the weights a caller uploaded (avd_cnn_set_weights,
+// avd_vit_set_weights) are state, not scratch, and stay
+void free_ws(Workspace& ws, bool keep_weights = false)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    uint16_t *kw = ws.d_cnn_w, *vw = ws.d_vit_w;
+    float *kb = ws.d_cnn_b, *vb = ws.d_vit_bias;
+    const int vhb = ws.vit_has_bias;
+    std::vector<size_t> woff = ws.cnn_w_off;
+    const size_t fcoff = ws.cnn_fc_off;
+    if (keep_weights) { ws.d_cnn_w = nullptr; ws.d_cnn_b = nullptr; ws.d_vit_w = nullptr; ws.d_vit_bias = nullptr; }
     F(ws.d_stage); F(ws.d_small); F(ws.d_rowbuf); F(ws.d_area); F(ws.d_hash); F(ws.d_ham); F(ws.d_lap); F(ws.d_lap_part);
     for (Geom& g : ws.geoms) F(g.d_tables);
     F(ws.d_clipstart);
@@ -57,6 +65,10 @@ void free_ws(Workspace& ws)
     for (int i = 0; i < 4; i++) F(ws.d_cnn_act[i]);
     if (ws.h_rec) (void)hipHostFree(ws.h_rec);
     ws = Workspace{};
+    if (keep_weights) {
+        ws.d_cnn_w = kw; ws.d_cnn_b = kb; ws.d_vit_w = vw; ws.d_vit_bias = vb; ws.vit_has_bias = vhb;
+        ws.cnn_w_off = woff; ws.cnn_fc_off = fcoff;
+    }
 }
 
 int check_geometry(avd_ctx* ctx, int n, int h, int w, int64_t row_stride, int64_t frame_stride)
@@ -750,7 +762,7 @@ static int impl_release_workspace(avd_ctx* ctx)
     if (!ctx) return AVD_ERR_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int e = impl_synchronize(ctx)) return e;
-    free_ws(ctx->ws);
+    free_ws(ctx->ws, true);
     return AVD_OK;
 }
 
@@ -846,6 +858,7 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     const size_t m = (size_t)n * 196;
     const size_t m_pad = (m + kGemmRowPad - 1) / kGemmRowPad * kGemmRowPad;   // the persistent GEMM reads whole 256-row tiles of A
     if (ws.vit_patch_elems < m_pad * 768) {
+        ws.vit_patch_elems = 0;                               // not valid again until the buffer exists
         if (int e = dev_alloc(ctx, ws.d_vit_patches, m_pad * 768)) return e;
         HIP_TRY(ctx, hipMemsetAsync(ws.d_vit_patches, 0, m_pad * 768 * sizeof(uint16_t), ctx->stream));
         ws.vit_patch_elems = m_pad * 768;
@@ -854,6 +867,7 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     const size_t esz = tokens_bf16 ? sizeof(uint16_t) : sizeof(float);
     if (tokens_mem == AVD_MEM_HOST) {
         if (ws.vit_token_elems < m * 768) {
+            ws.vit_token_elems = 0;
             if (int e = dev_alloc(ctx, ws.d_vit_tokens, m * 768)) return e;
             ws.vit_token_elems = m * 768;
         }
@@ -895,6 +909,7 @@ static int impl_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t 
     const uint8_t* d_wav = nullptr;
     if (int e = stage_input(ctx, reinterpret_cast<const uint8_t*>(wav), mem, (size_t)n * sizeof(float), &d_wav)) return e;
     if (ws.audio_out_elems < (size_t)nwin) {
+        ws.audio_out_elems = 0;
         if (int e = dev_alloc(ctx, ws.d_audio_out, (size_t)nwin)) return e;
         ws.audio_out_elems = (size_t)nwin;
     }

@@ -448,6 +448,7 @@ int cnn_reserve(avd_ctx* ctx, int n)
 {
     Workspace& ws = ctx->ws;
     if (n <= ws.cnn_frames) return AVD_OK;
+    ws.cnn_frames = 0;                                                   // not valid again until every buffer below exists
     const size_t act = act_elems((size_t)n * 112 * 112, 64);             // the largest activation (= n * 56 * 56 x 256)
     for (int i = 0; i < 4; i++) {
         if (int e = dev_alloc(ctx, ws.d_cnn_act[i], act)) return e;

@@ -10,6 +10,8 @@ RCCL all-gather of the 32-byte per-frame records reassembles all timelines: weak
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself -- a fresh
+`python -m torch.distributed.run` child, before this process has touched the GPU -- and relays rank 0's line.)
 
 Prints ONE JSON line on rank 0.  What is measured, and how:
   value / ms_per_step   W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks;
@@ -17,17 +19,23 @@ Prints ONE JSON line on rank 0.  What is measured, and how:
                         reported (min / max beside it: boxes and DVFS move a single 25 ms region by several percent).
                         --inflight clips are in flight per GPU, each on its own avd context AND its own copy of the
                         input in HBM (a service never analyses the same buffer three times at once).
-  roofline              the kernel with the largest share of the step: the fused Farneback level kernel at 320x320
-                        (all iterations of the level in one launch), timed with HIP events around the launch on the
-                        library's own stream while clips run ALONE (an exclusive pass before the timed region; with
-                        clips in flight an event-to-event time includes whatever shares the GPU).  achieved =
-                        ALGORITHMIC bytes per launch / average launch duration; traffic = HBM bytes per launch from
-                        the committed rocprofv3 --pmc passes (profiles/).
+  roofline              the kernel with the largest share of the step: the Farneback level kernel at 320x320 (fb_mode
+                        fast, the default and what `value` uses: one launch per blur iteration), timed with HIP events
+                        around its three launches on the library's own stream while clips run ALONE (an exclusive pass
+                        before the timed region; with clips in flight an event-to-event time includes whatever shares
+                        the GPU).  achieved = ALGORITHMIC bytes per launch / average launch duration; traffic = HBM
+                        bytes per launch from the committed rocprofv3 --pmc passes (profiles/).  `fb_modes` reports the
+                        exact level kernel (fb_mode exact: bit-identical to the oracle, one workgroup per pair) beside it.
+  short_clips_fps /     BASELINE.json configs[0]-sized clips (20 sampled 720p frames) and a configs[4] mixed-resolution
+  mixed_stream_fps      stream (720p / 1080p / 4K), handed over as BATCHES (avd_analyze_batch: one Farneback launch
+                        sequence over all pairs of a batch) and, for comparison, one clip per call.
   roofline_preprocess   the HBM-bound fused full-resolution kernel (north_star's ">= 60 % of HBM peak" target).
   config.sec_per_video  BASELINE.json's second metric: latency of one clip from decoded frames in PINNED HOST memory to
                         the final result (PCIe-inclusive); the HBM-resident latency is beside it.
   pcie_inclusive_fps    whole-job rate when every clip is handed over as a pinned host buffer (never `value`).
-  cpu_baseline          the CPU oracle (kind "port"), clip-parallel on the host cores, bounded sample.
+  cpu_baseline          the CPU oracle (kind "port"), clip-parallel on ALL host cores (one process per core, each the whole
+                        bounded sample, started together), with the one-thread figure beside it; measured BEFORE this
+                        process makes its first GPU call.
 """
 import argparse
 import json
@@ -45,7 +53,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 FP32_VALU_PEAK_TF = 157.3
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")     # HBM bytes per launch from rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")      # HBM bytes per launch from rocprofv3 --pmc passes (fast mode)
+PMC_FILE_EXACT = os.path.join(ROOT, "profiles", "r02_pmc.json")
+FP64_VALU_PEAK_TF = 78.6
 
 
 def preprocess_bytes_per_frame(h, w):
@@ -63,37 +73,75 @@ def fused_level_bytes(n_frames, iterations=3, w=320):
     return iterations * per_iter
 
 
-def load_pmc():
-    if os.path.exists(PMC_FILE):
-        with open(PMC_FILE) as fh:
+def load_pmc(path=None):
+    path = path or PMC_FILE
+    if os.path.exists(path):
+        with open(path) as fh:
             return json.load(fh)
     return {}
 
 
-def roofline_objects(n, h, w, stage, latency_ms):
-    """stage: avd_stage_ms of clips run alone: [preprocess, hash.., farneback+stats, copy-out, fused level 0, -]."""
-    pmc = load_pmc() if (n, h, w) == (120, 1080, 1920) else {}
+def oracle_op_counts(small_pair):
+    """Exact arithmetic-operation counts from the instrumented oracle (oracle/avd_oracle.c, avdo_ops_*): (a) everything
+    cv2 executes for one pair (both frames' pyramids and polynomial expansions included), (b) the blur iterations of
+    the 320 x 320 level of one pair = what the three launches of the level-0 kernel compute."""
+    from oracle import oracle as O
+    a, b = small_pair
+    whole = O.count_farneback_ops(a, b)
+    R0, R1 = O.poly_exp(a.astype(np.float32)), O.poly_exp(b.astype(np.float32))
+    flow = np.zeros((320, 320, 2), np.float32)
+    flow[..., 0] = 1.5
+    flow[..., 1] = -0.75                                       # a non-zero flow: every pixel takes the warped branch
+    lvl0 = O.count_level_ops(R0, R1, flow, 3)
+    return {"per_pair_as_cv2": whole, "level0_three_iterations_per_pair": lvl0,
+            "counted_in": "oracle/avd_oracle.c (OPS32 / OPS64 at the statements that execute; an fma counts 2)"}
+
+
+def roofline_objects(n, h, w, stage, latency_ms, mode="fast", ops=None):
+    """stage: avd_stage_ms of clips run alone: [preprocess, hash.., farneback+stats, copy-out, level 0 (all iterations), -].
+    mode "fast": three launches of k_fb_fast<320> (one per iteration); "exact": one launch of k_fb_level<320>."""
+    exact = mode == "exact"
+    pmc = load_pmc(PMC_FILE_EXACT if exact else PMC_FILE) if (n, h, w) == (120, 1080, 1920) else {}
     pairs = max(n - 1, 0)
-    fb_ms, pre_ms, stage_ms = float(stage[4]), float(stage[0]), float(stage[2])
-    alg = fused_level_bytes(n)
+    lvl_ms, pre_ms, stage_ms = float(stage[4]), float(stage[0]), float(stage[2])
+    launches = 1 if exact else 3
+    fb_ms = lvl_ms / launches                                   # average duration of ONE launch
+    alg = fused_level_bytes(n, 3 if exact else 1)
     ach = alg / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0
-    flops = pairs * 73e6 * (320 * 320 * 3) / ((320 * 320 + 160 * 160 + 80 * 80 + 40 * 40) * 3)   # level-0 share of ~73 Mflop per pair
-    dominant = {
-        "kernel": "k_fb_level<320> (Farneback level 0: normal equations + vertical / horizontal double running sums + 2x2 solve, "
-                  "3 iterations in one launch, one workgroup per pair, D never leaves the chip)",
-        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-        "traffic": pmc.get("k_fb_level<320>", {}).get("hbm_bytes"),
-        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(fb_ms, 4), "launches_per_step": 1,
-        "share_of_step": round(fb_ms / latency_ms, 4) if latency_ms > 0 else 0.0,
-        "bound_note": "measured (in-kernel stamps, ablations, tools/ldsdma_bench.hip; profiles/r02_experiments.md): the kernel is bound by "
-                      "VALU issue of the exact normal equations (two vertical waves per SIMD), by the dependent double-add chain of "
-                      "the horizontal scan and by what ONE CU can ingest from L2 (~40-60 GB/s; it pulls ~29), not by HBM -- the "
-                      "fraction of HBM peak is low BY CONSTRUCTION: 80 of the 136 B per pixel and iteration of the two-kernel "
-                      "path (the double intermediate D) no longer exist, and the kernel holds 119 of the 256 CUs",
-        "valu": {"flops": round(flops), "tflops": round(flops / (fb_ms * 1e-3) / 1e12, 2) if fb_ms > 0 else 0.0,
-                 "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF},
-        "timed": "HIP events around the launch on the library's stream, clips run alone before the timed region",
-    }
+    lvl_ops = (ops or {}).get("level0_three_iterations_per_pair")
+    valu = None
+    if lvl_ops:
+        f32, f64 = pairs * lvl_ops["f32"], pairs * lvl_ops["f64"]
+        t = lvl_ms * 1e-3
+        valu = {"f32_ops_per_level": f32, "f64_ops_per_level": f64,
+                "f32_tops": round(f32 / t / 1e12, 2) if t > 0 else 0.0, "f64_tops": round(f64 / t / 1e12, 2) if t > 0 else 0.0,
+                # time the vector units need at their peak rates (an add or a multiply is half an fma) over the time taken
+                "frac_of_vector_peak": round((f32 / (FP32_VALU_PEAK_TF * 0.5e12) + f64 / (FP64_VALU_PEAK_TF * 0.5e12)) / t, 4) if t > 0 else 0.0,
+                "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF, "fp64_vector_peak_tflops": FP64_VALU_PEAK_TF,
+                "note": "exact operation counts of the oracle for the same level (no fma contraction: cv2's arithmetic is mul + add); "
+                        "the peaks count an fma as two, so an add / mul stream can reach half of them"}
+    if exact:
+        dominant = {
+            "kernel": "k_fb_level<320> (fb_mode exact: normal equations + vertical / horizontal double RUNNING sums + 2x2 solve, 3 iterations in "
+                      "one launch, one workgroup per pair, bit-identical to the oracle)",
+            "bound": "valu", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "bound_note": "VALU issue of the vertical waves + the dependent double-add chain of the horizontal scan on 119 of 256 CUs "
+                          "(profiles/r02_experiments.md); the HBM figures are reported for comparison with the fast kernel"}
+    else:
+        dominant = {
+            "kernel": "k_fb_fast<320> (fb_mode fast: one blur iteration per launch, a pair spread over two column strips = 238 workgroups of "
+                      "12 waves; literal vertical running sums, horizontal 15-column windows summed directly in double, 2x2 solve)",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "bound_note": "per iteration every frame's polynomial expansion (20 B/px) and every pair's flow in + out (16 B/px) cross HBM: "
+                          "441 MB per launch at 119 pairs; PMC traffic 1.2x that (halo columns, partial lines).  Below the achievable "
+                          "~6.3 TB/s the remaining limiter is the texture-addresser / L1 path of the bilinear gathers and the per-step "
+                          "workgroup barrier (profiles/r03_experiments.md)"}
+    dominant.update({
+        "traffic": pmc.get("k_fb_level<320>" if exact else "k_fb_fast<320>", {}).get("hbm_bytes"),
+        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(fb_ms, 4), "launches_per_step": launches,
+        "share_of_step": round(lvl_ms / latency_ms, 4) if latency_ms > 0 else 0.0,
+        "valu": valu,
+        "timed": "HIP events around the level's launches on the library's stream, clips run alone before the timed region"})
     alg_pre = preprocess_bytes_per_frame(h, w) * n
     ach_pre = alg_pre / (pre_ms * 1e-3) / 1e9 if pre_ms > 0 else 0.0
     pre = {"kernel": "k_preprocess_vec (fused BGR->gray, INTER_AREA partials, INTER_LINEAR 320x320, Laplacian moments)",
@@ -104,65 +152,143 @@ def roofline_objects(n, h, w, stage, latency_ms):
     px = 320 * 320 + 160 * 160 + 80 * 80 + 40 * 40
     fb_alg = sum(fused_level_bytes(n, 3, ww) for ww in (320, 160, 80, 40))
     t = stage_ms * 1e-3
-    fb = {"stage": "Farneback (pyramid, polynomial expansion, 4 fused level kernels) + flow statistics", "avg_ms": round(stage_ms, 4),
+    whole = (ops or {}).get("per_pair_as_cv2")
+    fb = {"stage": "Farneback (pyramid, polynomial expansion, level kernels of 4 scales) + flow statistics", "avg_ms": round(stage_ms, 4),
           "algorithmic_bytes": fb_alg, "achieved": round(fb_alg / t / 1e9, 1) if t > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": round(fb_alg / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
-          "flops": pairs * 73e6, "tflops": round(pairs * 73e6 / t / 1e12, 2) if t > 0 else 0.0,
-          "fp32_vector_peak_tflops": FP32_VALU_PEAK_TF, "pixels_per_pair_all_levels": px,
+          "ops_per_pair_as_cv2": whole,
+          "tops_cv2_equivalent": round(pairs * (whole["f32"] + whole["f64"]) / t / 1e12, 2) if (whole and t > 0) else None,
+          "pixels_per_pair_all_levels": px,
           "traffic": pmc.get("farneback_stage", {}).get("hbm_bytes")}
     return dominant, pre, fb
 
 
 _CPU_CHILD = r"""
-import sys, time, json
+import os, sys, time, json
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 from oracle import oracle as O
 O.lib()
-clip = np.load(sys.argv[2], mmap_mode="r")
+clip = np.load(sys.argv[2], mmap_mode="r")            # shared page cache: no per-process copy of the sample
 meta = json.loads(sys.argv[3])
+print("ready", flush=True)
+while not os.path.exists(sys.argv[4]):                # all processes start together
+    time.sleep(0.002)
 t0 = time.perf_counter()
-O.analyze_sampled_frames(np.ascontiguousarray(clip), meta)
-print(time.perf_counter() - t0)
+O.analyze_sampled_frames(clip, meta)
+print(time.perf_counter() - t0, flush=True)
 """
 
 
+def usable_cores():
+    """Cores this process may actually use: the scheduler affinity, capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs quota) -- os.cpu_count() reports the HOST's logical CPUs, which a GPU box's container only gets a
+    share of (starting one process per host CPU there only oversubscribes the share).  -> (cores, how it was found)"""
+    import math
+    try:
+        cores, how = len(os.sched_getaffinity(0)), "scheduler affinity"
+    except (AttributeError, OSError):
+        cores, how = os.cpu_count() or 1, "os.cpu_count()"
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0 and per > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < cores:
+        cores, how = max(1, int(math.floor(quota + 1e-9))), f"cgroup CPU quota {quota:g}"
+    return cores, how
+
+
 def cpu_baseline(clip, meta, max_frames, procs):
-    """The CPU oracle (a port of the reference's cv2/numpy arithmetic; cv2's Farneback is single-threaded)
-    timed on a bounded sample of the same clip: (a) one thread, one clip -- the reference's per-request path;
-    (b) `procs` independent processes, one clip each, which is how a CPU box would be loaded for throughput
-    (clip-parallel, no GPU touched: fresh interpreters that only import numpy and the oracle)."""
+    """The CPU oracle (a port of the reference's cv2/numpy arithmetic; cv2's Farneback is single-threaded) timed on a
+    bounded sample of the same clip: (a) one thread, one clip -- the reference's per-request path; (b) one process per
+    host core, every one the whole sample, started together once all of them have loaded -- how a CPU box is loaded for
+    throughput (clip-parallel).  Fresh interpreters that only import numpy and the oracle; called before this process
+    makes its first GPU call."""
     import subprocess
     import tempfile
     from oracle import oracle as O
     O.lib()
     sample = np.ascontiguousarray(clip[:max_frames])
+    meta = dict(meta, duration=len(sample) / 2.0)
     t0 = time.perf_counter()
     O.analyze_sampled_frames(sample, meta)
     dt1 = time.perf_counter() - t0
     single = len(sample) / dt1
     out = {"value": round(single, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"first {len(sample)} sampled frames of the same clip, oracle/avd_oracle.c single thread, {dt1:.1f} s wall",
-           "host_cores_available": os.cpu_count()}
+           "single_thread_value": round(single, 3), "host_cores_available": os.cpu_count()}
     if procs > 1:
+        kids = []
         try:
             shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
             with tempfile.TemporaryDirectory(dir=shm) as td:
-                path = os.path.join(td, "sample.npy")
+                path, go = os.path.join(td, "sample.npy"), os.path.join(td, "go")
                 np.save(path, sample)
-                t0 = time.perf_counter()
-                kids = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, path, json.dumps(meta)],
+                kids = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, path, json.dumps(meta), go],
                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
-                ok = all(k.wait(timeout=600) == 0 for k in kids)
+                for k in kids:
+                    if k.stdout.readline().strip() != "ready":
+                        raise RuntimeError("a baseline process did not start")
+                t0 = time.perf_counter()
+                open(go, "w").close()
+                times = [float(k.stdout.readline()) for k in kids]
                 dtp = time.perf_counter() - t0
-            if ok:
-                out = {"value": round(procs * len(sample) / dtp, 2), "unit": "frames/s", "cores": procs, "kind": "port",
-                       "sample": f"{procs} processes x the first {len(sample)} sampled frames of the same clip (clip-parallel, "
-                                 f"oracle/avd_oracle.c, one thread each), {dtp:.1f} s wall incl. interpreter start-up",
-                       "single_thread_value": round(single, 3), "host_cores_available": os.cpu_count()}
+                for k in kids:
+                    k.wait(timeout=60)
+            out = {"value": round(procs * len(sample) / dtp, 2), "unit": "frames/s", "cores": procs, "kind": "port",
+                   "sample": f"{procs} processes (one per host core) x the first {len(sample)} sampled frames of the same clip, started "
+                             f"together (clip-parallel, oracle/avd_oracle.c, one thread each): {dtp:.1f} s wall, slowest process {max(times):.1f} s",
+                   "single_thread_value": round(single, 3), "host_cores_available": os.cpu_count()}
         except Exception as exc:                       # the single-thread figure stands; say why the other is missing
             out["multi_process_error"] = repr(exc)
+            for k in kids:
+                if k.poll() is None:
+                    k.kill()
     return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a fresh child
+    (`python -m torch.distributed.run`, one rank per GPU) and relay its output.  This process has not touched the GPU
+    (nothing GPU-related is imported before this point), so nothing is re-executed from an initialised process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, rank, world):
+    """--launch-check: the multi-rank plumbing without a GPU (CPU test of the launch contract): the ranks form the gloo
+    group, agree on the world size with one all-reduce, rank 0 prints a JSON line.  Not a measurement."""
+    import torch
+    import torch.distributed as tdist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        tdist.all_reduce(t)
+        seen = int(t.item())
+        tdist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus}))
+    return 0
 
 
 def main():
@@ -176,8 +302,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-procs", type=int, default=16,
-                    help="processes of the clip-parallel CPU baseline (capped at the host's cores; 1 = single thread only)")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="processes of the clip-parallel CPU baseline: 0 (default) = one per host core; 1 = single thread only")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-mode pass and the short-clip / mixed-stream batches")
+    ap.add_argument("--launch-check", action="store_true", help="multi-rank plumbing check without a GPU (gloo); not a measurement")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
     ap.add_argument("--no-vit", action="store_true", help="skip the extensions reported apart (ViT patch-embed GEMM, CNN forward, audio analyzer)")
@@ -195,14 +323,56 @@ def main():
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                 # before anything GPU-related is imported
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.launch_check:
+        sys.exit(launch_check(args, rank, world))
+
+    n, h, w = args.frames, args.height, args.width
+    meta = {"width": w, "height": h, "fps": 30.0, "duration": n / 2.0}
+    from avd_hip import synth                       # numpy only
+    clip = synth.make_clip(n, h, w, seed=args.seed + rank)          # synthetic, SURVEY.md 8(d) recipe
+
+    # CPU legs FIRST, before this process makes any GPU call: the baseline (its children are fresh interpreters) and the
+    # oracle's exact operation counts
+    cpu_base = ops = None
+    if rank == 0 and world == 1:
+        from oracle import oracle as O
+        two = np.stack([O.resize_linear(O.bgr2gray(f), 320, 320) for f in clip[:2]])
+        ops = oracle_op_counts(two)
+        if args.cpu_frames > 0:
+            cores, how = usable_cores()
+            nf = min(args.cpu_frames, n)
+            if args.cpu_procs > 0:
+                cpu_base = cpu_baseline(clip, meta, nf, max(1, min(args.cpu_procs, os.cpu_count() or 1)))
+            else:
+                # one process per usable core.  Where nothing on paper restricts a many-CPU host (a container may still only
+                # get a share of it), climb 16, 32, 64 ... and stop when doubling the processes no longer pays: the best
+                # figure and ITS process count are reported
+                p = min(cores, 16)
+                cpu_base = cpu_baseline(clip, meta, nf, p)
+                ladder = [{"procs": p, "frames_per_s": cpu_base["value"]}]
+                while p < cores:
+                    p = min(cores, 2 * p)
+                    nxt = cpu_baseline(clip, meta, nf, p)
+                    ladder.append({"procs": p, "frames_per_s": nxt["value"]})
+                    if "multi_process_error" in nxt or nxt["value"] < 1.3 * cpu_base["value"]:
+                        if nxt["value"] > cpu_base["value"] and "multi_process_error" not in nxt:
+                            cpu_base = nxt
+                        break
+                    cpu_base = nxt
+                cpu_base["process_ladder"] = ladder
+            cpu_base["cores_usable"] = cores
+            cpu_base["cores_usable_how"] = how
 
     import avd_hip
-    from avd_hip import synth, dist as avd_dist
+    from avd_hip import dist as avd_dist
     from avd_hip.timeline import records_to_result
     from avd_hip.pipeline import audio_unavailable
     from app.analyzers import fusion, heuristics_v2
@@ -229,9 +399,6 @@ def main():
             tdist.init_process_group("gloo")
     gather_dev = dev if args.backend == "nccl" else None
 
-    n, h, w = args.frames, args.height, args.width
-    meta = {"width": w, "height": h, "fps": 30.0, "duration": n / 2.0}
-    clip = synth.make_clip(n, h, w, seed=args.seed + rank)          # synthetic, SURVEY.md 8(d) recipe
     m = max(1, args.inflight)
     host = torch.from_numpy(clip)
     frames = [host.to(dev) for _ in range(m)]                        # one resident copy per in-flight slot
@@ -393,6 +560,97 @@ def main():
                  "speech_ratio": res_a["scores"]["speech_ratio"]}
         del dwave
 
+    # ---- fb_mode exact beside the default (fast): latency of a clip alone, level-0 time, throughput with clips in flight
+    exact = None
+    if not args.no_extras and world == 1:
+        ectx = [avd_hip.Context(dev_index) for _ in range(m)]
+        for c in ectx:
+            c.set_option("fb_mode", 0)
+            c.set_profiling(True)
+        erec = [np.zeros(n, avd_hip.RECORD_DTYPE) for _ in range(m)]
+        for _ in range(2):
+            ectx[0].analyze_frames_async(frames[0], erec[0]); ectx[0].synchronize()
+        el, est = [], np.zeros(6)
+        for _ in range(5):
+            t1 = time.perf_counter()
+            ectx[0].analyze_frames_async(frames[0], erec[0]); ectx[0].synchronize()
+            el.append(time.perf_counter() - t1)
+            est += np.array(ectx[0].stage_ms())
+        est /= 5
+        thr = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            q = []
+            for i in range(args.steps):
+                if len(q) == m:
+                    ectx[q.pop(0)].synchronize()
+                j = i % m
+                ectx[j].analyze_frames_async(frames[j], erec[j]); q.append(j)
+            while q:
+                ectx[q.pop(0)].synchronize()
+            thr.append(args.steps * n / (time.perf_counter() - t1))
+        exact = {"latency_ms": statistics.median(el) * 1e3, "stage": est, "fps": statistics.median(thr),
+                 "flow_mean_head": [float(v) for v in erec[0]["flow_mean"][1:4]]}
+        for c in ectx:
+            c.close()
+        del ectx
+
+    # ---- batches: configs[0]-sized short clips and a configs[4] mixed-resolution stream (avd_analyze_batch)
+    batches = None
+    if not args.no_extras and world == 1:
+        def stream_fps(make_calls, frames_per_round, rounds=6):
+            """make_calls(ctx_index) enqueues one round on that context; m rounds in flight"""
+            for j in range(m):
+                make_calls(j); ctxs[j].synchronize()
+            best = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                q = []
+                for i in range(rounds):
+                    if len(q) == m:
+                        ctxs[q.pop(0)].synchronize()
+                    make_calls(i % m); q.append(i % m)
+                while q:
+                    ctxs[q.pop(0)].synchronize()
+                best.append(rounds * frames_per_round / (time.perf_counter() - t1))
+            return statistics.median(best)
+
+        def one_by_one_fps(clips, rounds=2):
+            """the same clips, one avd_analyze_frames_async call per clip, m clips in flight"""
+            total = sum(int(c.shape[0]) for c in clips)
+            rb = [np.zeros(max(int(c.shape[0]) for c in clips), avd_hip.RECORD_DTYPE) for _ in range(m)]
+            best = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                q, i = [], 0
+                for _r in range(rounds):
+                    for c in clips:
+                        if len(q) == m:
+                            ctxs[q.pop(0)].synchronize()
+                        ctxs[i % m].analyze_frames_async(c, rb[i % m]); q.append(i % m); i += 1
+                while q:
+                    ctxs[q.pop(0)].synchronize()
+                best.append(rounds * total / (time.perf_counter() - t1))
+            return statistics.median(best)
+
+        short_src = [torch.from_numpy(synth.make_clip(20, 720, 1280, seed=50 + i)).to(dev) for i in range(3)]
+        short = [short_src[i % 3] for i in range(13)]                       # 13 clips x 20 frames = 259 consecutive pairs per batch
+        srec = [np.zeros(13 * 20, avd_hip.RECORD_DTYPE) for _ in range(m)]
+        short_batched = stream_fps(lambda j: ctxs[j].analyze_batch_async(short, srec[j]), 13 * 20)
+        short_single = one_by_one_fps(short)
+        mix_geo = [(20, 720, 1280)] * 6 + [(20, 1080, 1920)] * 4 + [(20, 2160, 3840)] * 2
+        order = np.random.default_rng(4).permutation(len(mix_geo))
+        mix_src = {g: torch.from_numpy(synth.make_clip(*g, seed=70 + g[1])).to(dev) for g in set(mix_geo)}
+        mixed = [mix_src[mix_geo[i]] for i in order]                        # shuffled 720p / 1080p / 4K stream, 240 frames
+        mrec = [np.zeros(20 * len(mixed), avd_hip.RECORD_DTYPE) for _ in range(m)]
+        mixed_batched = stream_fps(lambda j: ctxs[j].analyze_batch_async(mixed, mrec[j]), 20 * len(mixed), rounds=4)
+        mixed_single = one_by_one_fps(mixed, rounds=1)
+        batches = {"short": (short_batched, short_single), "mixed": (mixed_batched, mixed_single)}
+        del short_src, short, mix_src, mixed
+
     run(args.warmup)                  # W untimed warm-up steps in the timed region's own (pipelined) mode
     elapsed_all, timed_stage = [], np.zeros(6)
     result = fused = None
@@ -415,13 +673,13 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fps = lambda e: world * n * args.steps / e          # noqa: E731
-        dominant, pre, fb = roofline_objects(n, h, w, excl, latency_ms)
+        dominant, pre, fb = roofline_objects(n, h, w, excl, latency_ms, "fast", ops)
         out = {
             "metric": "sampled frames/sec analysed (1080p30 60 s clip, 2 fps sampling)",
             "value": round(fps(elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels; f32/f64 Farneback (cv2's own types)",
-            "data": "synthetic",
+            "data": "synthetic", "fb_mode_used": "fast",
             "repeats": {"n": len(elapsed_all), "statistic": "median", "value_min": round(fps(max(elapsed_all)), 2),
                         "value_max": round(fps(min(elapsed_all)), 2),
                         "ms_per_step_min": round(min(elapsed_all) / args.steps * 1e3, 4),
@@ -442,11 +700,11 @@ def main():
             "roofline_farneback_stage": fb,
             "stages_ms": {"preprocess": round(float(excl[0]), 4), "hash_hamming_records": round(float(excl[1]), 4),
                           "farneback_and_flow_stats": round(float(excl[2]), 4), "records_copy_out": round(float(excl[3]), 4),
-                          "fused_level0": round(float(excl[4]), 4),
+                          "level0_all_iterations": round(float(excl[4]), 4),
                           "note": "HIP events on the library's stream, clips run alone before the timed region"},
             "stages_ms_timed_region": {"preprocess": round(float(timed_stage[0]), 4),
                                        "farneback_and_flow_stats": round(float(timed_stage[2]), 4),
-                                       "fused_level0": round(float(timed_stage[4]), 4),
+                                       "level0_all_iterations": round(float(timed_stage[4]), 4),
                                        "note": "event-to-event times while other clips share the GPU"},
             "result_check": {"ai_timeline_head": [round(v, 6) for v in result["timeline"][:3]],
                              "dup_density": result["summary"]["dup_density"], **fused["result"]},
@@ -461,7 +719,7 @@ def main():
                 "what": "all kernels of one clip (preprocess, hash, pyramid, polynomial expansion, 4 level kernels, flow_up, statistics)",
                 "bound": "hbm", "traffic": whole, "algorithmic_bytes_input_only": preprocess_bytes_per_frame(h, w) * n,
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "note": "PMC HBM traffic per clip (profiles/r02_pmc.json) / ms_per_step with clips in flight"}
+                "note": "PMC HBM traffic per clip (profiles/r03_pmc.json) / ms_per_step with clips in flight"}
         if pcie_fps is not None:
             out["pcie_inclusive_fps"] = round(pcie_fps_inflight if pcie_fps_inflight is not None else pcie_fps, 1)
             out["pcie_inclusive_fps_one_clip_at_a_time"] = round(pcie_fps, 1)
@@ -517,10 +775,32 @@ def main():
                         "sums for every half-second window of a 60 s 16 kHz sound track in one call (reference audio.py:40-61), reported apart",
                 "windows": audio["windows"], "gpu_call_ms": round(audio["features_ms"], 3), "host_tail_ms": round(audio["tail_ms"], 3),
                 "windows_per_s": round(audio["windows"] / (audio["features_ms"] * 1e-3), 1), "f64_gflop_per_call_direct_form": round(audio["windows"] * 4001 * 8000 * 4 / 1e9, 2)}
-        if args.cpu_frames > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(clip, meta, min(args.cpu_frames, n), max(1, min(args.cpu_procs, os.cpu_count() or 1)))
-        else:
-            out["cpu_baseline"] = None
+        if exact is not None:
+            edom, _, efb = roofline_objects(n, h, w, exact["stage"], exact["latency_ms"], "exact", ops)
+            out["fb_modes"] = {
+                "value_uses": "fast",
+                "fast": {"what": "csrc/avd_fbfast.hip: flow identical to the oracle on well-posed inputs, within 1e-5 px / ai_susp 1e-6 (tests/test_gpu_fbfast.py)",
+                         "frames_per_s": out["value"], "sec_per_video_resident": round(latency_ms / 1e3, 6),
+                         "level0_all_iterations_ms": round(float(excl[4]), 4), "farneback_and_flow_stats_ms": round(float(excl[2]), 4),
+                         "flow_mean_head": [float(v) for v in recs[0]["flow_mean"][1:4]]},
+                "exact": {"what": "csrc/avd_fbfused.hip: bit-identical to the oracle, one workgroup per pair",
+                          "frames_per_s": round(exact["fps"], 2), "sec_per_video_resident": round(exact["latency_ms"] / 1e3, 6),
+                          "level0_all_iterations_ms": round(float(exact["stage"][4]), 4),
+                          "farneback_and_flow_stats_ms": round(float(exact["stage"][2]), 4),
+                          "flow_mean_head": exact["flow_mean_head"], "roofline": edom}}
+        if batches is not None:
+            out["short_clips_fps"] = {
+                "workload": "BASELINE.json configs[0]-sized clips: 20 sampled 720p frames each, resident in HBM, 13 clips per batch "
+                            "(avd_analyze_batch: one Farneback launch sequence over the 259 pairs of a batch), batches in flight as clips are",
+                "value": round(batches["short"][0], 1), "unit": "frames/s",
+                "one_clip_per_call": round(batches["short"][1], 1)}
+            out["mixed_stream_fps"] = {
+                "workload": "BASELINE.json configs[4]: shuffled stream of 20-frame clips, 6 x 720p + 4 x 1080p + 2 x 4K per batch of 240 frames "
+                            "(cached geometry tables, nothing allocated in steady state; the Farneback stage batches uniformly at 320 x 320)",
+                "value": round(batches["mixed"][0], 1), "unit": "frames/s",
+                "one_clip_per_call": round(batches["mixed"][1], 1)}
+        out["ops"] = ops
+        out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if use_dist:
         tdist.destroy_process_group()

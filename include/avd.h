@@ -186,7 +186,8 @@ int avd_cnn_conv(avd_ctx* ctx, const uint16_t* x, int n, int hin, int win, int c
  *   rms = sqrt(sumsq / length); zcr = float32(zero_cross) / float32(length - 1) / 2;
  *   flatness = exp(sum_log / nbins) / (sum_mag / nbins); rolloff = rolloff_index / max(1, nbins);
  *   centroid = sum_fmag / sum_mag          (mag = |rfft(seg * hanning)| + 1e-9, all sums in double)
- * and the scalar tail (audio.py:63-110) is host numpy (avd_hip/audio.py). */
+ * and the scalar tail (audio.py:63-110) is host numpy (avd_hip/audio.py).  sumsq is accumulated in double where
+ * audio.py:44 squares and averages in float32 (a deliberate deviation, inside 1e-6 of the reference's rms). */
 typedef struct avd_audio_window {
     double sumsq;            /* sum of seg^2                                             (audio.py:44) */
     double sum_log;          /* sum of log(mag)                                          (audio.py:50) */
@@ -219,7 +220,8 @@ int avd_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count
 int avd_wait_stream(avd_ctx* ctx, void* producer_stream);
 
 /* Free the context's scratch memory (about 1.5 GB after a 120-frame 1080p clip) but keep the context; the next
- * call reserves it again.  For services that keep a pool of idle contexts. */
+ * call reserves it again.  Weights uploaded with avd_cnn_set_weights / avd_vit_set_weights are state, not scratch: they
+ * stay.  For services that keep a pool of idle contexts. */
 int avd_release_workspace(avd_ctx* ctx);
 
 /* HIP-event timing of the work enqueued on ctx's stream between the two calls

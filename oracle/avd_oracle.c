@@ -52,6 +52,16 @@ static inline int reflect101(int p, int len) {
     return p;
 }
 
+/* ---------- operation counter (bench.py's roofline; SURVEY.md 8d asks for an exact count, not an estimate) ----------
+ * Every float / double add, subtract, multiply, divide and square root of the Farneback chain and of the flow statistics
+ * is tallied where it executes (an fma counts as 2; conversions, comparisons, floor and index arithmetic are not counted).
+ * Not thread-safe: one analysing thread per process, which is how this library is used. */
+static uint64_t g_ops[2];                     /* [0] float operations, [1] double operations */
+void avdo_ops_reset(void) { g_ops[0] = g_ops[1] = 0; }
+void avdo_ops_get(uint64_t out[2]) { out[0] = g_ops[0]; out[1] = g_ops[1]; }
+#define OPS32(n) (g_ops[0] += (uint64_t)(n))
+#define OPS64(n) (g_ops[1] += (uint64_t)(n))
+
 /* ---------- cvtColor BGR2GRAY, uint8 (video.py:5,43,51) ----------
  * RGB2Gray<uchar>: 15-bit fixed point, BY=3735 GY=19235 RY=9798, CV_DESCALE. */
 void avdo_bgr2gray(const uint8_t* bgr, int h, int w, int64_t row_stride, uint8_t* gray)
@@ -298,6 +308,7 @@ void avdo_flow_stats(const float* flow, int64_t npix, float* mean, float* var, f
         float a = fx * fx, b = fy * fy;
         mag[i] = sqrtf(a + b);
     }
+    OPS32(npix * 8 + 4);      /* magnitude (2 mul, add, sqrt), its sum, deviation (sub, mul), its sum; the two final divides are double */
     float s = avdo_np_sum_f32(mag, npix);
     *mean = (float)((double)s / (double)npix);
     float arrmean = s / (float)npix;
@@ -401,9 +412,11 @@ void avdo_gaussian_blur_f32(const float* src, int h, int w, int ksize, double si
                 D[x] = s;
             }
         }
+        OPS32((int64_t)w * (ksize == 3 ? 4 : 2 * ksize));
     }
     for (int y = 0; y < h; y++) {
         float* D = dst + (int64_t)y * w;
+        OPS32((int64_t)w * (2 + 3 * half));
         for (int x = 0; x < w; x++) {
             float c = tmp[(int64_t)y * w + x];
             float s = mac(c, kc[0], 0.f);
@@ -437,6 +450,7 @@ int avdo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst,
                     const float* S1 = S0 + sw;
                     dst[(int64_t)dy * dw + dx] = ((S0[0] + S0[1]) + (S1[0] + S1[1])) * 0.25f;
                 }
+            OPS32((int64_t)dh * dw * 4);
             return 0;
         }
     }
@@ -483,6 +497,7 @@ int avdo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst,
                 }
             }
         }
+        OPS32(2 * ((int64_t)xmax * cn * 3 + (int64_t)(dw - xmax) * cn) + (int64_t)dw * cn * 3);
         float b0 = beta[dy * 2], b1 = beta[dy * 2 + 1];
         const float *S0 = rows, *S1 = rows + (int64_t)dw * cn;
         float* D = dst + (int64_t)dy * dw * cn;
@@ -600,6 +615,8 @@ void avdo_poly_exp(const float* src, int h, int w, int n, double sigma, float* d
                 row[x * 3 + 2] = t2;
             }
         }
+        OPS32((int64_t)w * (1 + 8 * n) + (int64_t)w * (3 + 5 * n));      /* vertical pass; float part of the horizontal one */
+        OPS64((int64_t)w * (12 * n + 9));
         for (int x = 0; x < n * 3; x++) {
             row[-1 - x] = row[2 - x];
             row[w * 3 + x] = row[w * 3 + x - 3];
@@ -657,11 +674,13 @@ void avdo_update_matrices(const float* R0_, const float* R1, const float* flow_,
                 r4 = (R0[x * 5 + 2] + r4) * 0.5f;
                 r5 = (R0[x * 5 + 3] + r5) * 0.5f;
                 r6 = (R0[x * 5 + 4] + r6) * 0.25f;
+                OPS32(6 + 35 + 6);
             } else {
                 r2 = r3 = 0.f;
                 r4 = R0[x * 5 + 2];
                 r5 = R0[x * 5 + 3];
                 r6 = R0[x * 5 + 4] * 0.5f;
+                OPS32(1);
             }
             r2 = (R0[x * 5] - r2) * 0.5f;
             r3 = (R0[x * 5 + 1] - r3) * 0.5f;
@@ -674,6 +693,7 @@ void avdo_update_matrices(const float* R0_, const float* R1, const float* flow_,
                               (y < BORDER ? border[y] : 1.f) *
                               (y >= h - BORDER ? border[h - y - 1] : 1.f);
                 r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+                OPS32(8);
             }
             M[x * 5] = r4 * r4 + r6 * r6;
             M[x * 5 + 1] = (r4 + r5) * r6;
@@ -681,6 +701,7 @@ void avdo_update_matrices(const float* R0_, const float* R1, const float* flow_,
             M[x * 5 + 3] = r4 * r2 + r6 * r3;
             M[x * 5 + 4] = r6 * r2 + r5 * r3;
         }
+        OPS32((int64_t)w * (4 + 4 + 8 + 14));      /* fx, fy and their fractions; r2, r3; the flow terms; the five products of M */
     }
 }
 
@@ -697,16 +718,20 @@ void avdo_update_flow_blur(const float* R0, const float* R1, float* flow_, float
     double* vsum = vbuf + (m + 1) * 5;
     const float* srow0 = matM;
     for (x = 0; x < w * 5; x++) vsum[x] = srow0[x] * (m + 2);   /* float * int -> float */
+    OPS32((int64_t)w * 5);
     for (y = 1; y < m; y++) {
         srow0 = matM + (int64_t)imin(y, h - 1) * w * 5;
         for (x = 0; x < w * 5; x++) vsum[x] += srow0[x];
     }
+    OPS64((int64_t)w * 5 * (m - 1));
     for (y = 0; y < h; y++) {
         double g11, g12, g22, h1, h2;
         float* flow = flow_ + (int64_t)y * w * 2;
         srow0 = matM + (int64_t)imax(y - m - 1, 0) * w * 5;
         const float* srow1 = matM + (int64_t)imin(y + m, h - 1) * w * 5;
         for (x = 0; x < w * 5; x++) vsum[x] += srow1[x] - srow0[x];   /* float subtract */
+        OPS32((int64_t)w * 5);
+        OPS64((int64_t)w * 5 + 5 * m + (int64_t)w * (10 + 5 + 4 + 1 + 8));   /* vertical adds; row init; per pixel: window, scale, det, 1/det, two flows */
         for (x = 0; x < (m + 1) * 5; x++) {
             vsum[-1 - x] = vsum[4 - x];
             vsum[w * 5 + x] = vsum[w * 5 + x - 5];
@@ -785,6 +810,7 @@ int avdo_farneback(const uint8_t* prev, const uint8_t* next, int h, int w, float
             avdo_resize_linear_f32(prevFlow, ph, pw, 2, flow, height, width);
             float mul = (float)(1. / pyr_scale);
             for (size_t t = 0; t < (size_t)width * height * 2; t++) flow[t] = flow[t] * mul;
+            OPS32((int64_t)width * height * 2);
             if (MODEL(AVDO_MODEL_JITTER_FLOW)) ulp_jitter(flow, (size_t)width * height * 2, 77u + (uint32_t)k);
         }
         for (i = 0; i < 2; i++) {

@@ -67,6 +67,9 @@ def lib() -> C.CDLL:
         L.avdo_nv12_to_bgr24.restype = C.c_int
         L.avdo_yuv2rgb_consts.argtypes = [i64p]
         L.avdo_yuv2rgb_consts.restype = None
+        L.avdo_ops_reset.restype = None
+        L.avdo_ops_get.argtypes = [C.POINTER(C.c_uint64)]
+        L.avdo_ops_get.restype = None
         L.avdo_set_model.argtypes = [C.c_int]
         L.avdo_set_model.restype = None
         L.avdo_get_model.restype = C.c_int
@@ -178,6 +181,33 @@ def flow_stats(flow: np.ndarray):
     m, v = C.c_float(), C.c_float()
     lib().avdo_flow_stats(_p(flow, C.c_float), n, C.byref(m), C.byref(v), None)
     return np.float32(m.value), np.float32(v.value)
+
+
+def count_farneback_ops(prev: np.ndarray, nxt: np.ndarray) -> dict:
+    """Arithmetic operations the oracle executes for ONE frame pair: calcOpticalFlowFarneback (pyramid blur + resize,
+    polynomial expansion of both frames at four scales, matrices, three blur iterations per scale) + the flow statistics
+    (video.py:45-48).  -> {"f32": n, "f64": n}, counted in avd_oracle.c where the operations happen."""
+    L = lib()
+    L.avdo_ops_reset()
+    fl = farneback(prev, nxt)
+    flow_stats(fl)
+    out = (C.c_uint64 * 2)()
+    L.avdo_ops_get(out)
+    return {"f32": int(out[0]), "f64": int(out[1])}
+
+
+def count_level_ops(R0: np.ndarray, R1: np.ndarray, flow: np.ndarray, iterations: int = 3) -> dict:
+    """Operations of the blur iterations of ONE pyramid level of one pair (FarnebackUpdateMatrices + `iterations` x
+    FarnebackUpdateFlow_Blur, as avdo_farneback sequences them): what one level kernel of the HIP path computes."""
+    L = lib()
+    L.avdo_ops_reset()
+    fl = np.array(flow, np.float32, copy=True)
+    M = update_matrices(R0, R1, fl)
+    for i in range(iterations):
+        fl, M = update_flow_blur(R0, R1, fl, M, 15, i < iterations - 1)
+    out = (C.c_uint64 * 2)()
+    L.avdo_ops_get(out)
+    return {"f32": int(out[0]), "f64": int(out[1])}
 
 
 def np_sum_f32(a: np.ndarray) -> np.float32:

@@ -103,6 +103,43 @@ def test_window_features_against_numpy(ctx, seconds, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("win,n", [(1001, 2500), (999, 2997), (1002, 4000), (6, 20), (8190, 20000), (1, 5)])
+def test_window_lengths_that_are_not_multiples_of_four(ctx, win, n):
+    """avd.h lets the caller choose the window length (1..8192).  A length that is not a multiple of 4 has no quarter
+    period in its cosine table, so the sines come from a table of their own -- one per LENGTH: the full windows and the
+    shorter last window must not share it (full windows of 1001 samples used to read the 498-sample table of the last
+    window, past its end)."""
+    wav = (0.3 * np.random.default_rng(win).standard_normal(n)).astype(np.float32)
+    rec = ctx.audio_features(wav, win)
+    assert len(rec) == -(-n // win)
+    for i, r in enumerate(rec):
+        seg = wav[i * win:(i + 1) * win]
+        mag = np.abs(np.fft.rfft(seg * np.hanning(len(seg)))) + 1e-9
+        assert r["length"] == len(seg) and r["nbins"] == len(mag)
+        np.testing.assert_allclose(r["sum_mag"], np.sum(mag), rtol=1e-9)
+        np.testing.assert_allclose(r["sum_fmag"], np.sum(np.linspace(0.0, 1.0, len(mag)) * mag), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r["sum_log"], np.sum(np.log(mag)), rtol=1e-9, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_released_context_keeps_its_weights(ctx):
+    """avd_release_workspace gives scratch back; uploaded weights are state and survive it (a pooled context that is
+    trimmed and borrowed again must still know them)."""
+    import avd_hip
+    rng = np.random.default_rng(1)
+    w = (rng.standard_normal((768, 768)) * 0.02).astype(np.float32)
+    frames = rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    with avd_hip.Context(0) as c:
+        c.vit_set_weights(w, None)
+        a, _ = c.vit_patch_embed(frames)
+        c.analyze_frames(frames)
+        c.release_workspace()
+        b, _ = c.vit_patch_embed(frames)
+        assert np.array_equal(a, b)
+        assert len(c.analyze_frames(frames)) == 2
+
+
+@pytest.mark.gpu
 def test_analyze_against_the_reference_outputs(ctx, golden):
     for case in golden:
         if case.get("named") == "extract_fails":
