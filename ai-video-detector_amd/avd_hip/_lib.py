@@ -28,7 +28,7 @@ EXPORTS = (
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
     "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features",
     "avd_cnn_param_counts", "avd_cnn_set_weights", "avd_cnn_forward", "avd_cnn_conv",
-    "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records",
+    "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records", "avd_allgather_last_records",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
@@ -130,6 +130,7 @@ def load() -> C.CDLL:
     L.avd_comm_unique_id.argtypes = [vp]
     L.avd_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.avd_allgather_records.argtypes = [vp, vp, C.c_int, vp]
+    L.avd_allgather_last_records.argtypes = [vp, C.c_int, vp]
     L.avd_synchronize.argtypes = [vp]
     L.avd_analyze_batch.argtypes = [vp, vp, C.c_int, vp]
     L.avd_analyze_batch_async.argtypes = [vp, vp, C.c_int, vp]
@@ -413,6 +414,13 @@ class Context:
         assert local.dtype == RECORD_DTYPE
         out = np.zeros(len(local) * getattr(self, "_comm_world", 1), RECORD_DTYPE)
         self._check(self._L.avd_allgather_records(self._h, local.ctypes.data, len(local), out.ctypes.data))
+        return out
+
+    def allgather_last_records(self, count: int) -> np.ndarray:
+        """Gather the first ``count`` records of this context's last analysis call from every rank, straight from HBM
+        (enqueued behind the analysis on the context's stream; drains an outstanding asynchronous call)."""
+        out = np.zeros(count * getattr(self, "_comm_world", 1), RECORD_DTYPE)
+        self._check(self._L.avd_allgather_last_records(self._h, count, out.ctypes.data))
         return out
 
     def analyze_frames_async(self, frames, rec: np.ndarray):

@@ -1077,6 +1077,17 @@ int avd_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count
     return guarded(ctx, [&] { return comm_allgather_records(ctx, local, count, all); });
 }
 
+int avd_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    return guarded(ctx, [&] {
+        const int rc = comm_allgather_last_records(ctx, count, all);
+        // the stream has been drained: a pending asynchronous call's own records are complete as well
+        if (rc == 0 && ctx->pending_out) return impl_synchronize(ctx);
+        return rc;
+    });
+}
+
 int avd_wait_stream(avd_ctx* ctx, void* producer_stream) { return guarded(ctx, [&] { return impl_wait_stream(ctx, producer_stream); }); }
 int avd_release_workspace(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_release_workspace(ctx); }); }
 int avd_timer_start(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_timer_start(ctx); }); }

@@ -97,7 +97,8 @@ int comm_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int coun
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t mine = sizeof(avd_frame_record) * (size_t)count, total = mine * (size_t)ctx->comm_world;
     if (ctx->comm_bytes < mine + total) {
-        if (ctx->d_comm) { (void)hipFree(ctx->d_comm); ctx->d_comm = nullptr; ctx->comm_bytes = 0; }
+        if (ctx->d_comm) { (void)hipFree(ctx->d_comm); ctx->d_comm = nullptr; }
+        ctx->comm_bytes = 0;
         if (hipMalloc(&ctx->d_comm, mine + total) != hipSuccess) { ctx->err = "hipMalloc (record exchange)"; return AVD_ERR_NOMEM; }
         ctx->comm_bytes = mine + total;
     }
@@ -110,3 +111,31 @@ int comm_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int coun
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return AVD_OK;
 }
+
+// The same exchange straight from the device: the records of the context's LAST analysis call (ws.d_rec, written by
+// k_records on this stream) are the send buffer, the collective is enqueued behind them on the same stream, and ONE copy
+// brings the gathered block to the host.  No host round trip and no extra synchronisation before the collective.
+int comm_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all)
+{
+    if (count < 0 || (count > 0 && !all)) { ctx->err = "bad arguments"; return AVD_ERR_ARG; }
+    if (!ctx->comm) { ctx->err = "avd_comm_init has not been called on this context"; return AVD_ERR_ARG; }
+    if (count > ctx->last_n || !ctx->ws.d_rec) { ctx->err = "the last analysis call produced fewer records than asked for"; return AVD_ERR_ARG; }
+    if (count == 0) return AVD_OK;
+    Rccl* r = rccl(ctx->err);
+    if (!r) return AVD_ERR_DEVICE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t mine = sizeof(avd_frame_record) * (size_t)count, total = mine * (size_t)ctx->comm_world;
+    if (ctx->comm_bytes < mine + total) {
+        if (ctx->d_comm) { (void)hipFree(ctx->d_comm); ctx->d_comm = nullptr; }
+        ctx->comm_bytes = 0;
+        if (hipMalloc(&ctx->d_comm, mine + total) != hipSuccess) { ctx->err = "hipMalloc (record exchange)"; return AVD_ERR_NOMEM; }
+        ctx->comm_bytes = mine + total;
+    }
+    char* d_recv = static_cast<char*>(ctx->d_comm) + mine;
+    const int rc = r->allgather(ctx->ws.d_rec, d_recv, mine, /*ncclUint8*/ 1, ctx->comm, ctx->stream);
+    if (rc) return fail(ctx, r, "ncclAllGather", rc);
+    HIP_TRY(ctx, hipMemcpyAsync(all, d_recv, total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+

@@ -220,6 +220,7 @@ int comm_unique_id(std::string& err, void* id128);
 int comm_init(avd_ctx* ctx, int rank, int world, const void* id128);
 void comm_destroy(avd_ctx* ctx);
 int comm_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count, avd_frame_record* all);
+int comm_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all);
 // avd_audio.hip: per-window features of a mono float32 waveform (device pointers)
 int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, avd_audio_window* d_out, int nwin);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair

@@ -422,12 +422,15 @@ def main():
 
     def retire():
         j, _keep = pending.pop(0)
-        ctxs[j].synchronize()
-        stage[:] += np.array(ctxs[j].stage_ms())
-        rec = recs[j]
         if use_dist and args.collective == "native":
-            allrec = ctxs[j].allgather_records(rec)
+            # straight from the device records, enqueued behind the clip on its stream; drains the clip as well
+            allrec = ctxs[j].allgather_last_records(n)
+            rec = recs[j]
+            stage[:] += np.array(ctxs[j].stage_ms())
         else:
+            ctxs[j].synchronize()
+            stage[:] += np.array(ctxs[j].stage_ms())
+            rec = recs[j]
             allrec = avd_dist.gather_fixed(rec, device=gather_dev) if use_dist else rec
         # scalar tail (video.py:54-83) + fusion (fusion.py:16) for this rank's clip; other clips' records are local too
         video = records_to_result(allrec[rank * n:(rank + 1) * n], h * w, w, h, meta["fps"], meta["duration"])

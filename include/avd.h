@@ -210,6 +210,11 @@ int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int w
 int avd_comm_unique_id(void* id128);
 int avd_comm_init(avd_ctx* ctx, int rank, int world, const void* id128);
 int avd_allgather_records(avd_ctx* ctx, const avd_frame_record* local, int count, avd_frame_record* all);
+/* The same exchange straight from the device: the first `count` records of this context's LAST avd_analyze_* call
+ * (blocking or asynchronous) are gathered from where k_records left them in HBM -- the collective is enqueued on the
+ * context's stream behind the analysis, one copy brings the world * count gathered records to `all` (host).  Blocks until
+ * they are there; an outstanding asynchronous call is drained too (its own records buffer is filled). */
+int avd_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all);
 
 /* Stream ordering for AVD_MEM_DEVICE inputs.  A context launches on its own non-blocking stream, so device memory
  * that another stream is still writing (e.g. torch's current stream: a freshly computed tensor, a .contiguous()

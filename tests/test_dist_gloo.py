@@ -58,6 +58,50 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
     assert np.array_equal(np.load(tmp_path / "tl0.npy"), np.load(tmp_path / "tl1.npy"))
 
 
+def _cfg2_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "ai-video-detector_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import avd_hip
+    from avd_hip import dist as avd_dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips_per_rank, frames = 4, 6
+        local = np.zeros(clips_per_rank * frames, avd_hip.RECORD_DTYPE)
+        for j in range(clips_per_rank):
+            clip_id = rank * clips_per_rank + j                           # BASELINE.json configs[2]: clip c lives on rank c // 4
+            sl = slice(j * frames, (j + 1) * frames)
+            local["lap_sum"][sl] = clip_id * 1000 + np.arange(frames)
+            local["ham"][sl] = np.where(np.arange(frames) == 0, -1, clip_id)
+            local["flow_mean"][sl] = clip_id + np.arange(frames) / 16.0
+        allrec = avd_dist.gather_fixed(local)                             # ONE collective, equal counts
+        np.save(os.path.join(out_dir, f"cfg2_{rank}.npy"), allrec)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_cfg2_layout_eight_ranks_gloo(tmp_path):
+    """BASELINE.json configs[2]: 32 clips, whole clips per rank (4 each on 8 ranks), timelines reassembled with ONE
+    equal-count all-gather of the 32-byte records -- every rank ends up with all 32 clips in clip order."""
+    world, port = 8, _free_port()
+    mp.spawn(_cfg2_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    frames = 6
+    first = np.load(tmp_path / "cfg2_0.npy")
+    assert len(first) == 32 * frames
+    for c in range(32):
+        sl = slice(c * frames, (c + 1) * frames)
+        assert np.array_equal(first["lap_sum"][sl], c * 1000 + np.arange(frames)), c
+        assert first["ham"][sl][0] == -1 and np.all(first["ham"][sl][1:] == c)
+        assert np.array_equal(first["flow_mean"][sl], (c + np.arange(frames) / 16.0).astype(np.float32))
+    for r in range(1, world):
+        assert np.array_equal(np.load(tmp_path / f"cfg2_{r}.npy"), first), r
+
+
 def _gpu_worker(rank, world, port, out_dir):
     for p in (ROOT, os.path.join(ROOT, "ai-video-detector_amd")):
         if p not in sys.path:

@@ -219,5 +219,17 @@ def test_native_rccl_allgather_of_records(ctx):
         got = c.allgather_records(rec)
         assert np.array_equal(got, rec)
         assert np.array_equal(c.allgather_records(rec[:2]), rec[:2])    # another size re-uses the communicator
+        # straight from the device records of the context's last call (no host round trip before the collective), behind
+        # a blocking call and behind an asynchronous one (which it drains)
+        clip = synth.make_clip(5, 96, 160, seed=77, dup_every=2)
+        mine = c.analyze_frames(clip)
+        assert np.array_equal(c.allgather_last_records(5), mine) and np.array_equal(mine, rec)
+        buf = np.zeros(5, avd_hip.RECORD_DTYPE)
+        keep = c.analyze_frames_async(clip, buf)
+        got = c.allgather_last_records(5)
+        assert np.array_equal(got, rec) and np.array_equal(buf, rec)
+        assert np.array_equal(c.allgather_last_records(3), rec[:3])
+        with pytest.raises(avd_hip.AvdError):
+            c.allgather_last_records(6)                                 # more than the last call produced
         with pytest.raises(avd_hip.AvdError):
             c.comm_init(3, 2, uid)                                      # rank out of range
