@@ -46,23 +46,33 @@ constexpr int kM = 7;                 // (winsize - 1) / 2
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-template <int W, int NB>
+// W level size; NB 64-column blocks per strip; GD lead of the bilinear gather; NPB normal-equation waves per block (2: two
+// entries each per step, 4: one each); XPB solver waves per block (1: four columns per lane, 2: two columns per lane).
+// 2 + 1 + 1 waves per block is the throughput shape (320 px: the chip is full and total issue counts); 4 + 1 + 2 is the
+// latency shape for the small levels, where a launch is steps x the slowest wave of a step and most CUs are idle anyway.
+template <int W_, int NB_, int GD_ = 1, int NPB_ = 2, int XPB_ = 1>
 struct FGeo {
+    static constexpr int W = W_, NB = NB_, GD = GD_, NPB = NPB_, XPB = XPB_;
     static constexpr int H = W;
     static constexpr int SW = 64 * NB;               // lane columns of a strip
-    static constexpr int NWAVES = 4 * NB;
+    static constexpr int WPB = NPB + 1 + XPB;        // waves per block
+    static constexpr int NWAVES = WPB * NB;
+    static constexpr int EPS = 4 / NPB;              // entries per normal-equation wave and step
+    static constexpr int CPL = 4 / XPB;              // columns per solver lane
     static constexpr int NE = H + kM;                // entries of the vertical chain: image row min(e, H-1)
     static constexpr int NG = (NE + 3) / 4;          // groups of four entries
     static constexpr int T = ((NG + 2 + 3) / 4) * 4; // steps (= barriers): N on group t, C on t-1, X on t-2; the loops unroll by 4
-    static constexpr int ROWLEN = SW + 18;           // doubles per (row slot, channel) line; ROWLEN % 4 == 2: the four rows
-                                                     // of a solver instruction fall on different halves of a 32-byte bank pair
+    // doubles per (row slot, channel) line.  Four columns per lane: lanes stride 32 bytes, ROWLEN % 4 == 2 puts the four
+    // rows of a solver instruction on different halves of a 32-byte bank pair.  Two columns per lane: lanes stride 16
+    // bytes (a row's 16 lanes = one 256-byte bank row), ROWLEN % 32 == 0 keeps the rows of an instruction on it
+    static constexpr int ROWLEN = XPB == 1 ? SW + 18 : ((SW + 18 + 31) / 32) * 32;
     static constexpr int VS_SLOT = 5 * ROWLEN;
     static constexpr int VS_DOUBLES = 8 * VS_SLOT;   // ring of 8 image rows of vsum
     static constexpr int M_SLOT = 5 * 64;            // floats of one row of one block
     static constexpr int M_FLOATS = NB * 8 * M_SLOT; // ring of 8 rows per block
     static constexpr int LDS_DOUBLES = VS_DOUBLES + M_FLOATS / 2;
-    static_assert(ROWLEN % 4 == 2 && LDS_DOUBLES * 8 <= 163840, "LDS layout");
-    static_assert(H % 4 == 0, "whole groups of image rows");
+    static_assert(LDS_DOUBLES * 8 <= 163840 && NWAVES <= 16, "LDS layout, workgroup size");
+    static_assert(H % 4 == 0 && (NPB == 2 || NPB == 4) && (XPB == 1 || XPB == 2), "whole groups of image rows");
 };
 
 // workgroup barrier; debug builds (-DAVD_FBF_DEBUG) account the cycles a wave spends waiting at it
@@ -93,20 +103,20 @@ __device__ __forceinline__ void fb_barrier() { __syncthreads(); }
 // GD = entries of lead of the bilinear gather of R1 (its address needs the flow, so it cannot be issued arbitrarily early):
 // the gather of entry i + GD is issued while entry i is evaluated, the inputs (flow, R0) of entry i + 2 GD + 1 likewise.
 // Slots are statically indexed: the loop body is GD + 1 steps = 2 (GD + 1) entries.
-template <int W, int NB, int GD>
+template <typename Ge>
 __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
                                         int p, int x, int k, int lane, bool zf)
 {
-    using Ge = FGeo<W, NB>;
+    constexpr int W = Ge::W, GD = Ge::GD, EPS = Ge::EPS;
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
     const long long fbf_t0 = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int H = W, plane = W * H;
-    constexpr int NGS = GD + 1, NIS = 2 * NGS, U = NGS;   // gather slots, input slots, steps per loop body
+    constexpr int NGS = GD + 1, NIS = 2 * NGS, U = NIS / EPS;   // gather slots, input slots, steps per loop body
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
     const float sx = border_factor(x, W);
-    auto ent = [&](int i) { return 4 * (i >> 1) + 2 * k + (i & 1); };      // this wave's i-th entry
+    auto ent = [&](int i) { return 4 * (i / EPS) + EPS * k + (i % EPS); };  // this wave's i-th entry
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
     NeG2 g[NGS];
@@ -116,8 +126,8 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     for (int i = 0; i < GD; i++) ne_gather2(R, r1base, in[i], x, row_of(ent(i)), W, H, g[i], zf);
     auto work = [&](int t, int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int i = 2 * t + j, ii = 2 * q + j;                         // ii = i mod NIS, static
+        for (int j = 0; j < EPS; j++) {
+            const int i = EPS * t + j, ii = EPS * q + j;                     // ii = i mod NIS, static
             const int e = ent(i);
             // refills first: the gather GD entries ahead goes into the slot the previous entry released, the inputs
             // NIS - 1 entries ahead into the slot of the entry before this one (rows beyond the image clamp to the last)
@@ -157,10 +167,10 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
 // C: cv2's vertical running sums, literally.  Entry e brings image row min(e, H-1) in; from e = 7 on, row e - 15 (row 0
 // while the window still touches the top edge) leaves and the vsum row of image row e - 7 is published.
 // ------------------------------------------------------------------------------------------------------------------
-template <int W, int NB>
+template <typename Ge>
 __device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, int b, int lane)
 {
-    using Ge = FGeo<W, NB>;
+    constexpr int W = Ge::W;
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
     const long long fbf_t0 = __builtin_amdgcn_s_memtime();
@@ -237,20 +247,20 @@ __device__ __forceinline__ double recip_exact(double d)
 // chunk of four output columns).  The strip's lane column u holds image column clamp(xlo + u) with xlo = o0 - 7, and vsum
 // of lane column u sits at index u + 8 of its line: the window of output column o0 + i is lane columns i .. i + 14.
 // ------------------------------------------------------------------------------------------------------------------
-template <int W, int NB>
-__device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, int p, int b, int lane, int o0, int ow)
+template <typename Ge>
+__device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, int p, int b, int xi, int lane,
+                                           int o0, int ow)
 {
-    using Ge = FGeo<W, NB>;
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
     const long long fbf_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    constexpr int H = W, plane = W * H;
+    constexpr int W = Ge::W, H = W, plane = W * H, CPL = Ge::CPL, NV = 14 + CPL;
     const double scale = 1. / (15 * 15);
-    const int r = lane >> 4, j = 16 * b + (lane & 15);
-    const bool colok = 4 * j < ow;
-    float* fl = flow_out + (size_t)p * 2 * plane + o0 + 4 * j;
-    const double* vsrc = vsring + 8 + 4 * j;
+    const int r = lane >> 4, j = 16 * (Ge::XPB * b + xi) + (lane & 15);      // chunk of CPL columns: output columns CPL j ..
+    const bool colok = CPL * j < ow;
+    float* fl = flow_out + (size_t)p * 2 * plane + o0 + CPL * j;
+    const double* vsrc = vsring + 8 + CPL * j;
     for (int t4 = 0; t4 < Ge::T; t4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -263,27 +273,35 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
             if (t >= 2 && colok && y >= 0 && y < H) {
 #endif
                 const dbl2* s = reinterpret_cast<const dbl2*>(vsrc + (y & 7) * Ge::VS_SLOT);
-                double o[5][4];
+                double o[5][CPL];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    double v[18];
+                    double v[NV];
 #pragma unroll
-                    for (int i = 0; i < 9; i++) {
+                    for (int i = 0; i < NV / 2; i++) {
                         const dbl2 w2 = s[c * (Ge::ROWLEN / 2) + i];
                         v[2 * i] = w2.x; v[2 * i + 1] = w2.y;
                     }
-                    double A = v[3];
+                    if (CPL == 4) {
+                        double A = v[3];
 #pragma unroll
-                    for (int i = 4; i < 15; i++) A += v[i];
-                    const double p12 = v[1] + v[2], q2 = v[15] + v[16];
-                    o[c][0] = A + (v[0] + p12);
-                    o[c][1] = A + (p12 + v[15]);
-                    o[c][2] = A + (v[2] + q2);
-                    o[c][3] = A + (q2 + v[17]);
+                        for (int i = 4; i < 15; i++) A += v[i];
+                        const double p12 = v[1] + v[2], q2 = v[15] + v[16];
+                        o[c][0] = A + (v[0] + p12);
+                        o[c][1] = A + (p12 + v[15]);
+                        o[c][2] = A + (v[2] + q2);
+                        o[c][CPL - 1] = A + (q2 + v[NV - 1]);
+                    } else {
+                        double A = v[1];
+#pragma unroll
+                        for (int i = 2; i < 15; i++) A += v[i];
+                        o[c][0] = A + v[0];
+                        o[c][CPL - 1] = A + v[15];
+                    }
                 }
-                float fx[4], fy[4];
+                float fx[CPL], fy[CPL];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < CPL; i++) {
                     const double g11 = o[0][i] * scale, g12 = o[1][i] * scale, g22 = o[2][i] * scale;
                     const double h1 = o[3][i] * scale, h2 = o[4][i] * scale;
                     const double idet = recip_exact(g11 * g22 - g12 * g12 + 1e-3);
@@ -291,21 +309,25 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
                     fy[i] = (float)((g22 * h1 - g12 * h2) * idet);
                 }
                 float* dst = fl + y * W;
-                *reinterpret_cast<float4*>(dst) = make_float4(fx[0], fx[1], fx[2], fx[3]);
-                *reinterpret_cast<float4*>(dst + plane) = make_float4(fy[0], fy[1], fy[2], fy[3]);
+                if (CPL == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(fx[0], fx[1], fx[2 % CPL], fx[3 % CPL]);
+                    *reinterpret_cast<float4*>(dst + plane) = make_float4(fy[0], fy[1], fy[2 % CPL], fy[3 % CPL]);
+                } else {
+                    *reinterpret_cast<float2*>(dst) = make_float2(fx[0], fx[1]);
+                    *reinterpret_cast<float2*>(dst + plane) = make_float2(fy[0], fy[1]);
+                }
             }
         }
     }
     FBF_WAIT_OUT(threadIdx.x >> 6, 3, fbf_t0)
 }
 
-// NB = 2: 8 waves, 66 KiB of LDS -> two workgroups per CU (4 waves per SIMD: at most 128 registers)
-template <int W, int NB, int GD>
-__global__ __launch_bounds__((64 * FGeo<W, NB>::NWAVES), (NB == 2 && W == 320 ? 4 : 1)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
-                                                                      float* __restrict__ flow_out, int npairs, int nstrips, int ow,
-                                                                      int zero_first, int dbg)
+template <typename Ge>
+__global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
+                                                              float* __restrict__ flow_out, int npairs, int nstrips, int ow,
+                                                              int zero_first, int dbg)
 {
-    using Ge = FGeo<W, NB>;
+    constexpr int W = Ge::W, NB = Ge::NB;
     __shared__ __align__(16) double lds[Ge::LDS_DOUBLES];
     double* vsring = lds;
     float* mrings = reinterpret_cast<float*>(lds + Ge::VS_DOUBLES);
@@ -322,34 +344,35 @@ __global__ __launch_bounds__((64 * FGeo<W, NB>::NWAVES), (NB == 2 && W == 320 ? 
     const int width = o0 + ow <= W ? ow : W - o0;         // output columns of this strip (multiples of 4)
     // Waves w, w + 4, w + 8 of a workgroup share a SIMD.  Issue cycles per step: X ~ 900 (double), N ~ 550, C ~ 230: with
     // NB = 3 the SIMDs get {X, N1, C} of block 0, 1, 2 and {N0, N0, N0} -- 1700 / 1700 / 1700 / 1650 cycles
+    // role: 0 .. NPB-1 normal equations, NPB the chain, NPB+1 .. solvers
     int b, role;
-    if (NB == 3) {
+    if (NB == 3 && Ge::WPB == 4) {
         const int pos = wave & 3, grp = wave >> 2;
         b = pos == 3 ? grp : pos;
         role = pos == 3 ? 0 : (grp == 0 ? 3 : (grp == 1 ? 1 : 2));
     } else {
-        b = wave >> 2;
-        role = (wave + b) & 3;                            // rotate the roles over a block's four waves: every SIMD gets a mix
+        b = wave / Ge::WPB;
+        role = (wave % Ge::WPB + b) % Ge::WPB;            // rotate the roles over a block's waves: every SIMD gets a mix
     }
     const int xu = o0 - kM + 64 * b + lane;               // image column of this lane (clamped: replicated border)
     const int x = xu < 0 ? 0 : (xu > W - 1 ? W - 1 : xu);
     float* mring = mrings + b * 8 * Ge::M_SLOT;
-    if (role < 2) {
-        role_ne<W, NB, GD>(R, flow_in, mring, p, x, role, lane, zero_first != 0);
-    } else if (role == 2) {
+    if (role < Ge::NPB) {
+        role_ne<Ge>(R, flow_in, mring, p, x, role, lane, zero_first != 0);
+    } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
-        role_chain<W, NB>(mring, vsring, b, lane);
+        role_chain<Ge>(mring, vsring, b, lane);
     } else {
-        role_solve<W, NB>(vsring, flow_out, p, b, lane, o0, width);
+        role_solve<Ge>(vsring, flow_out, p, b, role - Ge::NPB - 1, lane, o0, width);
     }
 }
 
-template <int W, int NB, int GD = 1>
+template <typename Ge>
 void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, int np, int nstrips, int ow, int zero_first)
 {
     const int grid = 8 * ((np + 7) / 8) * nstrips;
     static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
-    hipLaunchKernelGGL((k_fb_fast<W, NB, GD>), dim3(grid), dim3(64 * FGeo<W, NB>::NWAVES), 0, stream, R, fin, fout, np, nstrips, ow, zero_first, dbg);
+    hipLaunchKernelGGL((k_fb_fast<Ge>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, np, nstrips, ow, zero_first, dbg);
 }
 
 }  // namespace
@@ -362,17 +385,19 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
     if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
-    case 320:
-        if (var == 1) launch_fast<320, 3, 1>(stream, R, flow_in, flow_out, np, 2, 160, zero_first);
-        else if (var == 2) launch_fast<320, 3, 3>(stream, R, flow_in, flow_out, np, 2, 160, zero_first);
-        else launch_fast<320, 3, 2>(stream, R, flow_in, flow_out, np, 2, 160, zero_first);
-        break;
+    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, np, 2, 160, zero_first); break;
     case 160:
-        if (var == 1) launch_fast<160, 2, 1>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
-        else launch_fast<160, 2, 2>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
+        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
+        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
         break;
-    case 80: launch_fast<80, 2>(stream, R, flow_in, flow_out, np, 1, 80, zero_first); break;
-    case 40: launch_fast<40, 1>(stream, R, flow_in, flow_out, np, 1, 40, zero_first); break;
+    case 80:
+        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, np, 1, 80, zero_first);
+        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, np, 1, 80, zero_first);
+        break;
+    case 40:
+        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, np, 1, 40, zero_first);
+        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, np, 1, 40, zero_first);
+        break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -2,7 +2,7 @@
 # round 3: PMC passes (separate, no tracing domains, program directly after --); tag = $1
 R=$GRAFT_REPO_ROOT; T=${1:-pmc}
 cd /tmp && export TMPDIR=/tmp
-P="--inflight 1 --steps 2 --warmup 1 --cpu-frames 0 --repeats 1 --no-pcie --no-vit"
+P="--inflight 1 --steps 2 --warmup 1 --cpu-frames 0 --repeats 1 --no-pcie --no-vit --no-extras"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r03_${T}_fetch -- python3 $R/bench.py $P > $R/gpurun_out/r03_${T}_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r03_${T}_write -- python3 $R/bench.py $P > $R/gpurun_out/r03_${T}_write.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/r03_${T}_sq -- python3 $R/bench.py $P > $R/gpurun_out/r03_${T}_sq.log 2>&1 || echo "sq pass failed"

@@ -2,7 +2,7 @@
 # round 3: memory-path counters of the level kernels (separate passes); tag = $1
 R=$GRAFT_REPO_ROOT; T=${1:-m}
 cd /tmp && export TMPDIR=/tmp
-P="--inflight 1 --steps 2 --warmup 1 --cpu-frames 0 --repeats 1 --no-pcie --no-vit"
+P="--inflight 1 --steps 2 --warmup 1 --cpu-frames 0 --repeats 1 --no-pcie --no-vit --no-extras"
 rocprofv3 -L > $R/gpurun_out/r03_counters_list.txt 2>&1
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TA_BUSY_avr TA_TA_BUSY_sum TA_BUSY_max TCP_TA_DATA_STALL_CYCLES_sum" "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
