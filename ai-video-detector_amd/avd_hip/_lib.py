@@ -26,7 +26,7 @@ EXPORTS = (
     "avd_analyze_frames_async", "avd_synchronize", "avd_analyze_batch", "avd_analyze_batch_async",
     "avd_wait_stream", "avd_release_workspace",
     "avd_preprocess_nv12", "avd_analyze_frames_nv12", "avd_analyze_frames_nv12_async",
-    "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features",
+    "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features", "avd_layernorm", "avd_softmax",
     "avd_cnn_param_counts", "avd_cnn_set_weights", "avd_cnn_forward", "avd_cnn_conv",
     "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records", "avd_allgather_last_records",
     "avd_timer_start", "avd_timer_stop", "avd_set_option",
@@ -127,6 +127,8 @@ def load() -> C.CDLL:
     L.avd_cnn_forward.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(C.c_float)]
     L.avd_cnn_conv.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.avd_audio_features.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int]
+    L.avd_layernorm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.POINTER(C.c_float)]
+    L.avd_softmax.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int, C.POINTER(C.c_float)]
     L.avd_comm_unique_id.argtypes = [vp]
     L.avd_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.avd_allgather_records.argtypes = [vp, vp, C.c_int, vp]
@@ -305,6 +307,45 @@ class Context:
         assert rec.dtype == RECORD_DTYPE and rec.size >= n and rec.flags.c_contiguous
         self._check(self._L.avd_analyze_frames_nv12_async(self._h, yp, cp, mem, n, h, w, yr, cr, yf, cf, rec.ctypes.data))
         return keep
+
+    # -- LayerNorm / softmax (extensions) -------------------------------------------------------------------------
+    def layernorm(self, x, gamma, beta, eps: float = 1e-5, timing_reps: int = 0, out=None):
+        """x: [rows, cols] float32 numpy array, or a contiguous float32 / bfloat16 torch-ROCm tensor (then ``out`` of the same
+        kind receives the result in HBM, default: a new tensor).  -> (y, kernel_ms or None)"""
+        g = np.ascontiguousarray(gamma, np.float32)
+        b = np.ascontiguousarray(beta, np.float32)
+        ms = C.c_float(0.0)
+        if _is_torch_tensor(x):
+            import torch
+            if not (x.is_cuda and x.is_contiguous() and x.dim() == 2):
+                raise ValueError("x must be a contiguous 2-D cuda tensor")
+            bf = {"torch.float32": 0, "torch.bfloat16": 1}[str(x.dtype)]
+            y = out if out is not None else torch.empty_like(x)
+            self._after_torch_stream(x)
+            self._check(self._L.avd_layernorm(self._h, x.data_ptr(), AVD_MEM_DEVICE, bf, x.shape[0], x.shape[1], g.ctypes.data, b.ctypes.data,
+                                              eps, y.data_ptr(), timing_reps, C.byref(ms)))
+            return y, (ms.value if timing_reps > 0 else None)
+        a = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(a)
+        self._check(self._L.avd_layernorm(self._h, a.ctypes.data, AVD_MEM_HOST, 0, a.shape[0], a.shape[1], g.ctypes.data, b.ctypes.data, eps,
+                                          y.ctypes.data, timing_reps, C.byref(ms)))
+        return y, (ms.value if timing_reps > 0 else None)
+
+    def softmax(self, x, timing_reps: int = 0):
+        """x: [rows, cols] float32 (numpy or contiguous cuda tensor) -> (probabilities of the same kind, kernel_ms or None)"""
+        ms = C.c_float(0.0)
+        if _is_torch_tensor(x):
+            import torch
+            if not (x.is_cuda and x.is_contiguous() and x.dim() == 2 and str(x.dtype) == "torch.float32"):
+                raise ValueError("x must be a contiguous 2-D float32 cuda tensor")
+            y = torch.empty_like(x)
+            self._after_torch_stream(x)
+            self._check(self._L.avd_softmax(self._h, x.data_ptr(), AVD_MEM_DEVICE, x.shape[0], x.shape[1], y.data_ptr(), timing_reps, C.byref(ms)))
+            return y, (ms.value if timing_reps > 0 else None)
+        a = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(a)
+        self._check(self._L.avd_softmax(self._h, a.ctypes.data, AVD_MEM_HOST, a.shape[0], a.shape[1], y.ctypes.data, timing_reps, C.byref(ms)))
+        return y, (ms.value if timing_reps > 0 else None)
 
     # -- ViT-B/16 patch embedding (extension, never part of ai_score) ------------------------------------------
     def vit_set_weights(self, weight: np.ndarray, bias=None):

@@ -895,6 +895,59 @@ static int impl_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n
     return AVD_OK;
 }
 
+// ---- LayerNorm / softmax (extensions; never part of ai_score) ------------------------------------------------------------
+// x / y: host or device (both the same side), gamma / beta: host float[cols].  Host operands are staged through the
+// extension scratch (d_vit_tokens, grown on demand).
+static int impl_rowop(avd_ctx* ctx, int op, const void* x, int mem, int bf16, int64_t rows, int cols, const float* gamma, const float* beta,
+                      float eps, void* y, int reps, float* ms)
+{
+    if (!ctx) return AVD_ERR_ARG;
+    if (rows < 0 || cols <= 0 || (rows > 0 && (!x || !y)) || (op == 0 && (!gamma || !beta))) { ctx->err = "bad arguments"; return AVD_ERR_ARG; }
+    if (mem != AVD_MEM_HOST && mem != AVD_MEM_DEVICE) { ctx->err = "mem must be AVD_MEM_HOST or AVD_MEM_DEVICE"; return AVD_ERR_ARG; }
+    if (rows == 0) return AVD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Workspace& ws = ctx->ws;
+    const size_t esz = (op == 0 && bf16) ? 2 : 4, bytes = (size_t)rows * cols * esz;
+    const size_t need_f = (2 * bytes + 2 * (size_t)cols * 4 + 3) / 4 + 64;       // x, y, gamma, beta in float units
+    const bool host = mem == AVD_MEM_HOST;
+    const size_t want = host ? need_f : (size_t)cols * 2 + 64;
+    if (ws.vit_token_elems < want) {
+        ws.vit_token_elems = 0;
+        if (int e = dev_alloc(ctx, ws.d_vit_tokens, want)) return e;
+        ws.vit_token_elems = want;
+    }
+    float* d_gb = ws.d_vit_tokens;                        // gamma | beta first (16-byte aligned), then x, then y
+    char* d_x = (char*)x;
+    char* d_y = (char*)y;
+    if (op == 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_gb, gamma, sizeof(float) * cols, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_gb + cols, beta, sizeof(float) * cols, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (host) {
+        d_x = (char*)(d_gb + 2 * (size_t)cols + ((64 - (2 * cols) % 64) % 64));
+        d_y = d_x + (bytes + 255) / 256 * 256;
+        HIP_TRY(ctx, hipMemcpyAsync(d_x, x, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    auto run = [&]() -> int {
+        return op == 0 ? launch_layernorm(ctx, d_x, d_y, bf16, rows, cols, d_gb, d_gb + cols, eps)
+                       : launch_softmax(ctx, (const float*)d_x, (float*)d_y, rows, cols);
+    };
+    if (int e = run()) return e;
+    if (reps > 0 && ms) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int r = 0; r < reps; r++)
+            if (int e = run()) return e;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+        *ms = t / reps;
+    }
+    if (host) HIP_TRY(ctx, hipMemcpyAsync(y, d_y, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AVD_OK;
+}
+
 // ---- audio analyzer (row N3) -------------------------------------------------------------------------------------
 static int impl_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows)
 {
@@ -1054,6 +1107,17 @@ int avd_vit_patch_embed(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h,
                         void* tokens, int tokens_mem, int tokens_bf16, int timing_reps, float* gemm_ms)
 {
     return guarded(ctx, [&] { return impl_vit_patch_embed(ctx, bgr, mem, n, h, w, row_stride, frame_stride, tokens, tokens_mem, tokens_bf16, timing_reps, gemm_ms); });
+}
+
+int avd_layernorm(avd_ctx* ctx, const void* x, int mem, int bf16, int64_t rows, int cols, const float* gamma, const float* beta, float eps,
+                  void* y, int timing_reps, float* ms)
+{
+    return guarded(ctx, [&] { return impl_rowop(ctx, 0, x, mem, bf16, rows, cols, gamma, beta, eps, y, timing_reps, ms); });
+}
+
+int avd_softmax(avd_ctx* ctx, const float* x, int mem, int64_t rows, int cols, float* y, int timing_reps, float* ms)
+{
+    return guarded(ctx, [&] { return impl_rowop(ctx, 1, x, mem, 0, rows, cols, nullptr, nullptr, 0.f, y, timing_reps, ms); });
 }
 
 int avd_audio_features(avd_ctx* ctx, const float* wav, int mem, int64_t n, int win, avd_audio_window* windows, int max_windows)

@@ -229,3 +229,6 @@ int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, flo
 // avd_fbfast.hip: ONE blur iteration of one pyramid level, a pair spread over several workgroups (column strips), the
 // horizontal window sums formed directly in double (the vertical chain stays literal); flow_in != flow_out
 int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int np, int zero_first);
+// avd_norm.hip (extensions): LayerNorm over rows of 256..2048 values, softmax over rows of logits; device pointers
+int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps);
+int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols);

@@ -544,6 +544,21 @@ def main():
                "top1_head": [int(v) for v in logits[:3].argmax(axis=1)]}
         del wts, bss
 
+    # LayerNorm over the patch-embed tokens and softmax over the CNN's logits (north_star's stack; extensions, reported apart)
+    norm = None
+    if not args.no_vit and world == 1:
+        rows = 960 * 196
+        tokb = torch.randn((rows, 768), dtype=torch.float32, device=dev).to(torch.bfloat16)
+        gam, bet = np.ones(768, np.float32), np.zeros(768, np.float32)
+        outb = torch.empty_like(tokb)
+        ctxs[0].layernorm(tokb, gam, bet, timing_reps=3, out=outb)
+        _, ln_ms = ctxs[0].layernorm(tokb, gam, bet, timing_reps=20, out=outb)
+        lg = torch.randn((n, 1000), dtype=torch.float32, device=dev)
+        ctxs[0].softmax(lg, timing_reps=3)
+        _, sm_ms = ctxs[0].softmax(lg, timing_reps=50)
+        norm = {"rows": rows, "ln_ms": ln_ms, "softmax_ms": sm_ms, "softmax_rows": n}
+        del tokb, outb, lg
+
     # audio analyzer, reported apart: the clip's 60 s sound track as 120 half-second windows
     audio = None
     if not args.no_vit and world == 1:
@@ -772,6 +787,17 @@ def main():
                 "hbm_note": "PMC traffic (profiles/r02_pmc_extensions.json, 120 frames): bf16 activations written and read once per layer are "
                             "63 MB per frame -- a layer-by-layer forward is bound by this traffic (~1.5 ms per 120 frames at 5 TB/s), not by the matrix pipe",
                 "timed": "5 whole forward passes (BGR frames in HBM to logits) between two HIP events on the library's stream"}
+        if norm is not None:
+            lnb = norm["rows"] * 768 * 4                             # bf16 tokens read once and written once
+            gbs = lnb / (norm["ln_ms"] * 1e-3) / 1e9
+            out["layernorm_tokens"] = {
+                "kernel": "k_layernorm<3, bf16> (LayerNorm over the 768 values of a patch-embed token: one wave per row, the row in registers, "
+                          "wave-shuffle reductions, float32 statistics; one pass over HBM)",
+                "extension": "no reference counterpart; north_star's conv / GEMM / LayerNorm / softmax stack; not part of value / ai_score",
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "rows": norm["rows"], "algorithmic_bytes_per_launch": lnb, "avg_launch_ms": round(norm["ln_ms"], 4),
+                "softmax_1000_logits": {"rows": norm["softmax_rows"], "avg_launch_ms": round(norm["softmax_ms"], 4),
+                                        "note": "120 rows of 4 KB: a launch-latency-sized kernel (one wave per row)"}}
         if audio is not None:
             out["audio_analyzer"] = {
                 "what": "avd_audio_features: RMS / zero crossings / Hann + 8000-point real DFT in double (80 x 100 two-step, exact twiddle table) / flatness, roll-off, centroid "

@@ -179,6 +179,19 @@ int avd_cnn_forward(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, int h, int
 int avd_cnn_conv(avd_ctx* ctx, const uint16_t* x, int n, int hin, int win, int cin, const uint16_t* w, const float* bias,
                  int cout, int ksize, int stride, int relu, const uint16_t* residual, uint16_t* y);
 
+/* LayerNorm and softmax -- the remaining elements of north_star's "conv / GEMM / LayerNorm / softmax stack"; BUILD-DEFINED
+ * EXTENSIONS like the two above (the reference has no learned model), never part of ai_score.  One wave per row, the row
+ * held in registers, wave-level shuffle reductions, one pass over HBM.
+ * avd_layernorm: y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dimension (biased variance, float32
+ * statistics: torch.nn.functional.layer_norm); x / y [rows][cols] float32 (bf16 = 0) or bf16 bit patterns (bf16 = 1), both
+ * host or both device (mem); cols in {256, 512, 768, 1024, 2048} (768 = the ViT-B/16 token width); gamma / beta host
+ * float[cols].  avd_softmax: y = exp(x - max) / sum over rows of cols float32 logits (cols % 4 == 0, <= 4096; 1000 = the
+ * CNN's classes).  If timing_reps > 0 and ms != NULL the kernel alone is launched timing_reps more times between two HIP
+ * events and its mean duration is returned (bench hook). */
+int avd_layernorm(avd_ctx* ctx, const void* x, int mem, int bf16, int64_t rows, int cols, const float* gamma, const float* beta,
+                  float eps, void* y, int timing_reps, float* ms);
+int avd_softmax(avd_ctx* ctx, const float* x, int mem, int64_t rows, int cols, float* y, int timing_reps, float* ms);
+
 /* Audio analyzer: the per-window loop of reference app/analyzers/audio.py:40-61 for every window of a
  * mono float32 waveform at once.  wav: n samples (host or device); win: samples per window (the reference uses
  * int(sr * 0.5) = 8000 at 16 kHz; at most 8192); windows: host array of ceil(n / win) records, filled in order (the
