@@ -173,13 +173,101 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------------------
 struct PolyPtrs { const float* I[AVD_FB_LEVELS]; float* R[AVD_FB_LEVELS]; };
 
+constexpr int kPolyRows = 8;                             // image rows per workgroup of the full-resolution scale
+
+// The 320-px scale (three quarters of the stage's pixels): a workgroup walks kPolyRows consecutive rows.  A lane keeps the
+// eleven rows of its column that the vertical pass reads in registers and slides them (one new load per row instead of
+// eleven, 18 / 8 loads per row with the halo), the two LDS buffers alternate, so a row costs ONE workgroup barrier, and the
+// coalesced 16-byte stores of row i - 1 are issued while row i is in its horizontal pass.  Same arithmetic per pixel as
+// the one-row form below (which still serves the three small scales): bit-identical.
+__device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, float* __restrict__ out, int y0, const FbConsts* __restrict__ C,
+                                                float (*rowb)[3][S + 80], float (*outb)[S * 5])
+{
+    constexpr int w = S, h = S;
+    const int x = threadIdx.x;
+    const float* g = C->g + 5; const float* xg = C->xg + 5; const float* xxg = C->xxg + 5;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float win[11];                                       // rows y - 5 .. y + 5 of this column (clamped: replicate border)
+#pragma unroll
+    for (int q = 0; q < 10; q++) win[q + 1] = img[min(max(y0 - 5 + q, 0), h - 1) * w + x];
+#pragma unroll 1
+    for (int i = 0; i < kPolyRows; i++) {
+        const int y = y0 + i, par = i & 1;
+#pragma unroll
+        for (int q = 0; q < 10; q++) win[q] = win[q + 1];
+        win[10] = img[min(y + 5, h - 1) * w + x];
+        {
+            float t0 = win[5] * g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 1; q <= 5; q++) {
+                const float a = win[5 - q], bb = win[5 + q];
+                const float p = a + bb;
+                t0 = t0 + g[q] * p;
+                t1 = t1 + xg[q] * (bb - a);
+                t2 = t2 + xxg[q] * p;
+            }
+            float* r0s = rowb[par][0]; float* r1s = rowb[par][1]; float* r2s = rowb[par][2];
+            r0s[x + 5] = t0; r1s[x + 5] = t1; r2s[x + 5] = t2;
+            if (x == 0)
+                for (int q = 0; q < 5; q++) { r0s[q] = t0; r1s[q] = t1; r2s[q] = t2; }
+            if (x == w - 1)
+                for (int q = 0; q < 5; q++) { r0s[w + 5 + q] = t0; r1s[w + 5 + q] = t1; r2s[w + 5 + q] = t2; }
+        }
+        __syncthreads();
+        if (i > 0) {                                     // row i - 1 is complete in outb[par ^ 1]: 1600 floats = 400 16-byte pieces
+            f4* dst = reinterpret_cast<f4*>(out + (int64_t)(y - 1) * w * 5);
+            const f4* srcv = reinterpret_cast<const f4*>(outb[par ^ 1]);
+            __builtin_nontemporal_store(srcv[x], dst + x);
+            if (x < S * 5 / 4 - 320) __builtin_nontemporal_store(srcv[x + 320], dst + x + 320);
+        }
+        const float* r0 = rowb[par][0] + x + 5; const float* r1 = rowb[par][1] + x + 5; const float* r2 = rowb[par][2] + x + 5;
+        double b1 = (double)(r0[0] * g[0]), b2 = 0, b3 = (double)(r1[0] * g[0]), b4 = 0, b5 = (double)(r2[0] * g[0]), b6 = 0;
+#pragma unroll
+        for (int q = 1; q <= 5; q++) {
+            const double tg = (double)(r0[q] + r0[-q]);
+            b1 += tg * (double)g[q];
+            b4 += tg * (double)xxg[q];
+            b2 += (double)((r0[q] - r0[-q]) * xg[q]);
+            b3 += (double)((r1[q] + r1[-q]) * g[q]);
+            b6 += (double)((r1[q] - r1[-q]) * xg[q]);
+            b5 += (double)((r2[q] + r2[-q]) * g[q]);
+        }
+        float* o = outb[par] + x * 5;
+        o[0] = (float)(b3 * C->ig11);
+        o[1] = (float)(b2 * C->ig11);
+        o[2] = (float)(b1 * C->ig03 + b5 * C->ig33);
+        o[3] = (float)(b1 * C->ig03 + b4 * C->ig33);
+        o[4] = (float)(b6 * C->ig55);
+    }
+    __syncthreads();
+    {
+        f4* dst = reinterpret_cast<f4*>(out + (int64_t)(y0 + kPolyRows - 1) * w * 5);
+        const f4* srcv = reinterpret_cast<const f4*>(outb[(kPolyRows - 1) & 1]);
+        __builtin_nontemporal_store(srcv[x], dst + x);
+        if (x < S * 5 / 4 - 320) __builtin_nontemporal_store(srcv[x + 320], dst + x + 320);
+    }
+}
+
 __global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const FbConsts* __restrict__ C)
 {
-    __shared__ float row[3][S + 80];                     // per sub-row: w + 10 entries (5 replicated on either side)
-    __shared__ __align__(16) float outb[S * 5];
-    // scale k: w = 320 >> k, rows per workgroup 1 << k, workgroups n * 320 / 4^k (padded to a multiple of 8: within a scale
-    // consecutive workgroups -- overlapping 11-row windows -- share an XCD)
-    int b = blockIdx.x, k = 0;
+    __shared__ float rowb[2][3][S + 80];                 // per sub-row: w + 10 entries (5 replicated on either side); two buffers
+    __shared__ __align__(16) float outbb[2][S * 5];
+    float (*row)[S + 80] = rowb[0];
+    float* outb = outbb[0];
+    // the 320-px scale first: n * 320 / kPolyRows workgroups of kPolyRows rows (consecutive row bands of a frame share an XCD)
+    {
+        const int wgs0 = n * (S / kPolyRows), cnt0 = ((wgs0 + 7) >> 3) << 3;
+        if ((int)blockIdx.x < cnt0) {
+            const int per = cnt0 >> 3, lid = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+            if (lid >= wgs0) return;
+            const int f = lid / (S / kPolyRows), y0 = (lid - f * (S / kPolyRows)) * kPolyRows;
+            polyexp_rows320(P.I[0] + (int64_t)f * S * S, P.R[0] + (int64_t)f * S * S * 5, y0, C, rowb, outbb);
+            return;
+        }
+    }
+    // scale k >= 1: w = 320 >> k, rows per workgroup 1 << k, workgroups n * 320 / 4^k (padded to a multiple of 8: within a
+    // scale consecutive workgroups -- overlapping 11-row windows -- share an XCD)
+    int b = (int)blockIdx.x - ((((n * (S / kPolyRows)) + 7) >> 3) << 3), k = 1;
     for (; k < AVD_FB_LEVELS; k++) {
         const int cnt = ((n * (S >> (2 * k)) + 7) >> 3) << 3;
         if (b < cnt) break;
@@ -781,7 +869,8 @@ __device__ __forceinline__ float chunk_total(const float* part)
 
 // PASS 0: per-buffer pairwise sums of mag.  PASS 1: of (mag - mean)^2, mean = sum/N in float32.
 // grid (kNChunk, npairs); part[pair][pass][kNChunk]
-template <int PASS>
+// MAG: the buffer holds |flow| already (written by the last launch of the fast level kernel) instead of the two flow planes
+template <int PASS, bool MAG = false>
 __global__ __launch_bounds__(256) void k_stats_chunk(const float* __restrict__ flow, float* __restrict__ part)
 {
     __shared__ float buf[kChunk];
@@ -790,17 +879,21 @@ __global__ __launch_bounds__(256) void k_stats_chunk(const float* __restrict__ f
     const int p = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int base = ch * kChunk;
     const int len = min(kChunk, AVD_NPIX - base);
-    const float* fxp = flow + (int64_t)p * 2 * AVD_NPIX + base;
+    const float* fxp = flow + (int64_t)p * (MAG ? 1 : 2) * AVD_NPIX + base;
     const float* fyp = fxp + AVD_NPIX;
     float mean32 = 0.f;
     if (PASS == 1) mean32 = chunk_total(part + (int64_t)p * 2 * kNChunk) / (float)AVD_NPIX;   // _var: f32 true_divide
     for (int i = tid * 4; i < len; i += 1024) {
-        const float4 fx = *reinterpret_cast<const float4*>(fxp + i), fy = *reinterpret_cast<const float4*>(fyp + i);
         float4 mg;
-        mg.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
-        mg.y = sqrtf(fx.y * fx.y + fy.y * fy.y);
-        mg.z = sqrtf(fx.z * fx.z + fy.z * fy.z);
-        mg.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
+        if (MAG) {
+            mg = *reinterpret_cast<const float4*>(fxp + i);
+        } else {
+            const float4 fx = *reinterpret_cast<const float4*>(fxp + i), fy = *reinterpret_cast<const float4*>(fyp + i);
+            mg.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
+            mg.y = sqrtf(fx.y * fx.y + fy.y * fy.y);
+            mg.z = sqrtf(fx.z * fx.z + fy.z * fy.z);
+            mg.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
+        }
         if (PASS == 1) {
             float d;
             d = mg.x - mean32; mg.x = d * d;
@@ -903,10 +996,10 @@ void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int
     const int wgs = n * (S / 8 + S / 16 + S / 32 + S / 64);
     hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3]);
     PolyPtrs P;
-    int grid = 0;
+    int grid = ((n * (S / kPolyRows) + 7) >> 3) << 3;      // the 320-px scale: kPolyRows rows per workgroup
     for (int k = 0; k < AVD_FB_LEVELS; k++) {
         P.I[k] = g.pyr[k]; P.R[k] = g.poly[k];
-        grid += ((n * (S >> (2 * k)) + 7) >> 3) << 3;
+        if (k > 0) grid += ((n * (S >> (2 * k)) + 7) >> 3) << 3;
     }
     hipLaunchKernelGGL(k_polyexp_all, dim3(grid), dim3(320), 0, g.stream, P, n, C);
 }
@@ -953,6 +1046,7 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
     const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     if (g.prof) ctx->kern_ev_used = 0;
     const int np = n - 1;
+    ctx->ws.mag_valid = ctx->fb_mode == 1;
     pyramid_and_polyexp(ctx, g, d_small, n);
     for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
         const int w = S >> k, h = S >> k;
@@ -974,7 +1068,8 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             float* b = ctx->ws.d_flow2[k] + (size_t)pair_off * 2 * plane;
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
             for (int it = 0; it < 3; it++) {
-                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], a, b, np, k == AVD_FB_LEVELS - 1 && it == 0)) return e;
+                float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
+                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], a, b, mag, np, k == AVD_FB_LEVELS - 1 && it == 0)) return e;
                 float* t = a; a = b; b = t;
             }
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
@@ -1009,8 +1104,14 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
     const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     const int np = n - 1;
     const float* fl = ctx->ws.flow_res[0] ? ctx->ws.flow_res[0] : g.flow[0];
-    hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
-    hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
+    if (ctx->ws.mag_valid && ctx->ws.d_mag) {
+        const float* mg = ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX;
+        hipLaunchKernelGGL((k_stats_chunk<0, true>), dim3(kNChunk, np), dim3(256), 0, stream, mg, g.part);
+        hipLaunchKernelGGL((k_stats_chunk<1, true>), dim3(kNChunk, np), dim3(256), 0, stream, mg, g.part);
+    } else {
+        hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
+        hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
+    }
     hipLaunchKernelGGL(k_stats_final, dim3((np + 63) / 64), dim3(64), 0, stream, (const float*)g.part, g.stats, np);
     if (g.flow_il)
         launch1d(k_flow_interleave, (int64_t)np * AVD_NPIX, 256, stream, fl, g.flow_il, (int64_t)np * AVD_NPIX);

@@ -248,8 +248,8 @@ __device__ __forceinline__ double recip_exact(double d)
 // of lane column u sits at index u + 8 of its line: the window of output column o0 + i is lane columns i .. i + 14.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename Ge>
-__device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, int p, int b, int xi, int lane,
-                                           int o0, int ow)
+__device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, float* __restrict__ mag_out,
+                                           int p, int b, int xi, int lane, int o0, int ow)
 {
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
@@ -308,6 +308,16 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
                     fx[i] = (float)((g11 * h2 - g12 * h1) * idet);
                     fy[i] = (float)((g22 * h1 - g12 * h2) * idet);
                 }
+                // last iteration of the 320-px level: |flow| as np.sqrt(fx * fx + fy * fy) forms it in float32 (video.py:46), for the
+                // statistics kernels -- they then read 4 bytes per pixel twice instead of 8, and the flow only once, here
+                if (mag_out) {
+                    float mg[CPL];
+#pragma unroll
+                    for (int i = 0; i < CPL; i++) { const float a2 = fx[i] * fx[i], b2 = fy[i] * fy[i]; mg[i] = sqrtf(a2 + b2); }
+                    float* md = mag_out + (size_t)p * plane + y * W + o0 + CPL * j;
+                    if (CPL == 4) *reinterpret_cast<float4*>(md) = make_float4(mg[0], mg[1], mg[2 % CPL], mg[3 % CPL]);
+                    else *reinterpret_cast<float2*>(md) = make_float2(mg[0], mg[1]);
+                }
                 float* dst = fl + y * W;
                 if (CPL == 4) {
                     *reinterpret_cast<float4*>(dst) = make_float4(fx[0], fx[1], fx[2 % CPL], fx[3 % CPL]);
@@ -324,8 +334,8 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
 
 template <typename Ge>
 __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
-                                                              float* __restrict__ flow_out, int npairs, int nstrips, int ow,
-                                                              int zero_first, int dbg)
+                                                              float* __restrict__ flow_out, float* __restrict__ mag_out, int npairs,
+                                                              int nstrips, int ow, int zero_first, int dbg)
 {
     constexpr int W = Ge::W, NB = Ge::NB;
     __shared__ __align__(16) double lds[Ge::LDS_DOUBLES];
@@ -363,40 +373,42 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
         role_chain<Ge>(mring, vsring, b, lane);
     } else {
-        role_solve<Ge>(vsring, flow_out, p, b, role - Ge::NPB - 1, lane, o0, width);
+        role_solve<Ge>(vsring, flow_out, mag_out, p, b, role - Ge::NPB - 1, lane, o0, width);
     }
 }
 
 template <typename Ge>
-void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, int np, int nstrips, int ow, int zero_first)
+void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* mag, int np, int nstrips, int ow, int zero_first)
 {
     const int grid = 8 * ((np + 7) / 8) * nstrips;
     static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
-    hipLaunchKernelGGL((k_fb_fast<Ge>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, np, nstrips, ow, zero_first, dbg);
+    hipLaunchKernelGGL((k_fb_fast<Ge>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, np, nstrips, ow, zero_first, dbg);
 }
 
 }  // namespace
 
 // ONE blur iteration of one pyramid level for `np` pairs: flow_in -> flow_out (different buffers), R = polynomial expansions
 // of np + 1 frames ([frame][y][x][5]), flows planar [pair][2][y][x]
-int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int np, int zero_first)
+// mag_out (320-px level, last iteration; else null): float[pair][320][320] receives |flow|
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int np,
+                   int zero_first)
 {
     if (np <= 0) return 0;
     if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
-    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, np, 2, 160, zero_first); break;
+    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 160, zero_first); break;
     case 160:
-        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
-        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, np, 2, 80, zero_first);
+        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first);
+        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first);
         break;
     case 80:
-        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, np, 1, 80, zero_first);
-        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, np, 1, 80, zero_first);
+        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first);
+        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first);
         break;
     case 40:
-        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, np, 1, 40, zero_first);
-        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, np, 1, 40, zero_first);
+        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first);
+        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first);
         break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
     }

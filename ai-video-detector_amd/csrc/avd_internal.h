@@ -124,6 +124,8 @@ struct Workspace {
     float* d_flow[AVD_FB_LEVELS] = {};    // [n-1][2][hL*wL]  planar
     float* d_flow2[AVD_FB_LEVELS] = {};   // second flow buffer of a level: the fast level kernel (avd_fbfast.hip) ping-pongs
     const float* flow_res[AVD_FB_LEVELS] = {};   // where the last call left the final flow of each level (d_flow or d_flow2)
+    float* d_mag = nullptr;               // [n-1][320*320] |flow| of the full-resolution level (written by the fast level kernel)
+    int mag_valid = 0;                    // d_mag holds the magnitudes of the chunk being processed
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
@@ -228,7 +230,8 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
 int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first);
 // avd_fbfast.hip: ONE blur iteration of one pyramid level, a pair spread over several workgroups (column strips), the
 // horizontal window sums formed directly in double (the vertical chain stays literal); flow_in != flow_out
-int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int np, int zero_first);
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int np,
+                   int zero_first);
 // avd_norm.hip (extensions): LayerNorm over rows of 256..2048 values, softmax over rows of logits; device pointers
 int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps);
 int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols);
