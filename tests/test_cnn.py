@@ -3,8 +3,9 @@ reference counterpart (the reference has no learned model, SURVEY.md section 0.1
 the CPU (torch.nn.functional on the host, plumbing only): the same bf16-rounded weights, every activation rounded to bf16
 where the HIP path stores it, accumulation in float32.  Tolerances (stated here; north_star's 1e-4 is for the reference's
 own outputs): one layer -- the two float32 accumulation orders can land on opposite sides of a bf16 rounding boundary, so
-|error| <= 2^-7 |ref| + 2e-3 (one bf16 ulp); the whole network (53 layers of such roundings) -- logits within 3 % of the
-largest |logit| and a correlation above 0.999."""
+|error| <= 2^-7 |ref| + 2e-3 (one bf16 ulp); the whole network (53 layers of such roundings) -- logits within 0.8 % of the
+largest |logit| (budget derived in test_forward_against_float32, with a negative control: a missing residual in the last
+block is 5x outside it) and a correlation above 0.9999."""
 import numpy as np
 import pytest
 
@@ -78,7 +79,9 @@ def input_reference(frames):
     return np.ascontiguousarray(a.transpose(0, 3, 1, 4, 2, 5).reshape(n, 3, 224, 224))
 
 
-def forward_reference(frames, weights, biases):
+def forward_reference(frames, weights, biases, break_last_residual=False):
+    """break_last_residual: a deliberately WRONG network (the last block forgets its residual) -- the negative control of
+    the end-to-end test: its logits must differ from the right ones by far more than the test's tolerance."""
     convs = topology()
     wo = bo = 0
     params = []
@@ -106,6 +109,8 @@ def forward_reference(frames, weights, biases):
             a1 = conv(x, li)
             a2 = conv(a1, li + 1)
             res = conv(x, li + 3, relu=False) if b == 0 else x
+            if break_last_residual and st == len(DEPTH) - 1 and b == depth - 1:
+                res = None
             x = conv(a2, li + 2, res=res)
             li += 4 if b == 0 else 3
     pooled = x.mean(dim=(2, 3))
@@ -180,8 +185,17 @@ def test_forward_against_float32(ctx):
     want = forward_reference(frames, weights, biases)
     scale = float(np.abs(want).max())
     assert scale > 0.1                                # the seeded network does produce a signal
-    assert float(np.abs(logits - want).max()) <= 0.03 * scale
-    assert np.corrcoef(logits.ravel(), want.ravel())[0, 1] > 0.999
+    # Budget: a layer's two float32 accumulation orders flip < 2 % of its bf16 roundings by one ulp (2^-8 relative, asserted
+    # per layer above); 53 such layers in sequence, errors adding like a random walk and averaged over 49 pixels by the
+    # pooling: sqrt(53 * 0.02) * 2^-8 ~ 0.4 % of an activation's magnitude at worst, i.e. well under 1 % of the largest logit.
+    err = float(np.abs(logits - want).max()) / scale
+    print(f"[cnn] end-to-end max |logit error| = {err:.5f} of the largest |logit|")
+    assert err <= 0.008
+    assert np.corrcoef(logits.ravel(), want.ravel())[0, 1] > 0.9999
+    # negative control: a network whose LAST block forgets its residual (the smallest structural error there is) lies far
+    # outside that tolerance, so this comparison would notice it
+    wrong = forward_reference(frames, weights, biases, break_last_residual=True)
+    assert float(np.abs(wrong - want).max()) / scale > 5 * 0.008
     # batch independence: a frame alone gives the same logits as inside the batch
     alone, _ = ctx.cnn_forward(frames[1:2])
     assert np.array_equal(alone[0], logits[1])
