@@ -34,7 +34,7 @@ res = {"label": label, "note": "mean per launch; FETCH_SIZE / WRITE_SIZE in KiB,
                                "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide); SQ_* cycle counters count quad-cycles",
        "kernels": kernels}
 # short names bench.py looks up
-for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_fb_fast<320>", r"k_fb_fast<320"), ("k_preprocess_vec", r"k_preprocess_vec"),
+for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_fb_fast<320>", r"k_fb_fast<(FGeo<)?320"), ("k_preprocess_vec", r"k_preprocess_vec"),
                    ("k_preprocess_nv12", r"k_preprocess_nv12")):
     for name, k in kernels.items():
         if re.search(pat, name) and "hbm_bytes" in k:
