@@ -510,6 +510,13 @@ def main():
             c0.analyze_frames_nv12(hy, hc)
         nv12 = {"pre_ms": statistics.median(pre), "host_fps": 3 * n / (time.perf_counter() - t1),
                 "flow_mean_head": [round(float(v), 6) for v in rec_nv["flow_mean"][1:3]]}
+        nl = []
+        for _ in range(5):                                     # latency of one clip from pinned NV12 surfaces to its records + host tail
+            t1 = time.perf_counter()
+            rnv = c0.analyze_frames_nv12(hy, hc)
+            records_to_result(rnv, h * w, w, h, meta["fps"], meta["duration"])
+            nl.append(time.perf_counter() - t1)
+        nv12["host_latency_ms"] = statistics.median(nl) * 1e3
         del dy, dc
 
     # ViT-B/16 patch-embed MFMA stage (a build-defined extension, NOT part of `value`): the GEMM
@@ -709,6 +716,8 @@ def main():
                        "sec_per_video_note": ("one clip alone, from decoded frames in pinned host memory to the fused result "
                                               "(PCIe-inclusive, median of 5)" if host_lat_ms is not None else
                                               "one clip alone, frames resident in HBM (--no-pcie)"),
+                       "sec_per_video_nv12": None if nv12 is None else round(nv12["host_latency_ms"] / 1e3, 6),
+                       "sec_per_video_nv12_note": "the same clip handed over as pinned NV12 decoder surfaces (1.5 B per pixel over PCIe, median of 5)",
                        "sec_per_video_resident": round(latency_ms / 1e3, 6),
                        "sec_per_video_resident_note": f"one clip alone, frames already in HBM (median of {n_excl}, before the timed region)",
                        "decoded_frame_equivalent_fps": round(fps(elapsed) * 15, 1),
