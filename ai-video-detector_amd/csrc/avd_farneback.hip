@@ -185,28 +185,35 @@ __device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, f
 {
     constexpr int w = S, h = S;
     const int x = threadIdx.x;
-    const float* g = C->g + 5; const float* xg = C->xg + 5; const float* xxg = C->xxg + 5;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    float win[11];                                       // rows y - 5 .. y + 5 of this column (clamped: replicate border)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    // the kernel is VALU-bound (profiles/r03_experiments.md): the taps live in registers for all rows of the workgroup, as
+    // floats and -- where cv2 multiplies a double by them -- as doubles; pairs of float products that share a factor are
+    // formed as two-component vectors (v_pk_mul_f32 / v_pk_add_f32: one instruction for two IEEE operations, same results)
+    float g[6], xg[6], xxg[6];
+    double gd[6], xxgd[6];
 #pragma unroll
-    for (int q = 0; q < 10; q++) win[q + 1] = img[min(max(y0 - 5 + q, 0), h - 1) * w + x];
-#pragma unroll 1
-    for (int i = 0; i < kPolyRows; i++) {
+    for (int q = 0; q <= 5; q++) { g[q] = C->g[5 + q]; xg[q] = C->xg[5 + q]; xxg[q] = C->xxg[5 + q]; gd[q] = (double)g[q]; xxgd[q] = (double)xxg[q]; }
+    const double ig11 = C->ig11, ig03 = C->ig03, ig33 = C->ig33, ig55 = C->ig55;
+    float win[11 + kPolyRows];                           // rows y0 - 5 .. y0 + kPolyRows + 4 of this column (clamped: replicate border)
+#pragma unroll
+    for (int q = 0; q < 10; q++) win[q] = img[min(max(y0 - 5 + q, 0), h - 1) * w + x];
+#pragma unroll
+    for (int i = 0; i < kPolyRows; i++) {                // fully unrolled: the window is a static slice win[i .. i + 10]
         const int y = y0 + i, par = i & 1;
-#pragma unroll
-        for (int q = 0; q < 10; q++) win[q] = win[q + 1];
-        win[10] = img[min(y + 5, h - 1) * w + x];
+        win[i + 10] = img[min(y + 5, h - 1) * w + x];
         {
-            float t0 = win[5] * g[0], t1 = 0.f, t2 = 0.f;
+            f2 t02 = f2{win[i + 5] * g[0], 0.f};
+            float t1 = 0.f;
 #pragma unroll
             for (int q = 1; q <= 5; q++) {
-                const float a = win[5 - q], bb = win[5 + q];
+                const float a = win[i + 5 - q], bb = win[i + 5 + q];
                 const float p = a + bb;
-                t0 = t0 + g[q] * p;
+                t02 = t02 + f2{g[q], xxg[q]} * f2{p, p};  // t0 = t0 + g[q] * p;  t2 = t2 + xxg[q] * p
                 t1 = t1 + xg[q] * (bb - a);
-                t2 = t2 + xxg[q] * p;
             }
             float* r0s = rowb[par][0]; float* r1s = rowb[par][1]; float* r2s = rowb[par][2];
+            const float t0 = t02.x, t2 = t02.y;
             r0s[x + 5] = t0; r1s[x + 5] = t1; r2s[x + 5] = t2;
             if (x == 0)
                 for (int q = 0; q < 5; q++) { r0s[q] = t0; r1s[q] = t1; r2s[q] = t2; }
@@ -217,27 +224,38 @@ __device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, f
         if (i > 0) {                                     // row i - 1 is complete in outb[par ^ 1]: 1600 floats = 400 16-byte pieces
             f4* dst = reinterpret_cast<f4*>(out + (int64_t)(y - 1) * w * 5);
             const f4* srcv = reinterpret_cast<const f4*>(outb[par ^ 1]);
+#if !(defined(AVD_POLY_ABL) && (AVD_POLY_ABL & 8))   // timing experiment: no stores of the 320-px scale
             __builtin_nontemporal_store(srcv[x], dst + x);
             if (x < S * 5 / 4 - 320) __builtin_nontemporal_store(srcv[x + 320], dst + x + 320);
+#else
+            if (x == 0) __builtin_nontemporal_store(srcv[x], dst + x);
+#endif
         }
         const float* r0 = rowb[par][0] + x + 5; const float* r1 = rowb[par][1] + x + 5; const float* r2 = rowb[par][2] + x + 5;
         double b1 = (double)(r0[0] * g[0]), b2 = 0, b3 = (double)(r1[0] * g[0]), b4 = 0, b5 = (double)(r2[0] * g[0]), b6 = 0;
+#if defined(AVD_POLY_ABL) && (AVD_POLY_ABL & 4)      // timing experiment: no horizontal pass (results are wrong)
+        b2 = r0[1]; b4 = r1[1]; b6 = r2[1];
+#else
 #pragma unroll
         for (int q = 1; q <= 5; q++) {
-            const double tg = (double)(r0[q] + r0[-q]);
-            b1 += tg * (double)g[q];
-            b4 += tg * (double)xxg[q];
-            b2 += (double)((r0[q] - r0[-q]) * xg[q]);
-            b3 += (double)((r1[q] + r1[-q]) * g[q]);
-            b6 += (double)((r1[q] - r1[-q]) * xg[q]);
-            b5 += (double)((r2[q] + r2[-q]) * g[q]);
+            const float r0p = r0[q], r0m = r0[-q], r1p = r1[q], r1m = r1[-q], r2p = r2[q], r2m = r2[-q];
+            const double tg = (double)(r0p + r0m);
+            b1 += tg * gd[q];
+            b4 += tg * xxgd[q];
+            const f2 d26 = (f2{r0p, r1p} - f2{r0m, r1m}) * f2{xg[q], xg[q]};     // (r0[q] - r0[-q]) * xg[q], (r1[q] - r1[-q]) * xg[q]
+            const f2 s35 = (f2{r1p, r2p} + f2{r1m, r2m}) * f2{g[q], g[q]};       // (r1[q] + r1[-q]) * g[q],  (r2[q] + r2[-q]) * g[q]
+            b2 += (double)d26.x;
+            b3 += (double)s35.x;
+            b6 += (double)d26.y;
+            b5 += (double)s35.y;
         }
+#endif
         float* o = outb[par] + x * 5;
-        o[0] = (float)(b3 * C->ig11);
-        o[1] = (float)(b2 * C->ig11);
-        o[2] = (float)(b1 * C->ig03 + b5 * C->ig33);
-        o[3] = (float)(b1 * C->ig03 + b4 * C->ig33);
-        o[4] = (float)(b6 * C->ig55);
+        o[0] = (float)(b3 * ig11);
+        o[1] = (float)(b2 * ig11);
+        o[2] = (float)(b1 * ig03 + b5 * ig33);
+        o[3] = (float)(b1 * ig03 + b4 * ig33);
+        o[4] = (float)(b6 * ig55);
     }
     __syncthreads();
     {

@@ -179,4 +179,40 @@ __device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x,
     M[4] = r6 * r2 + r5 * r3;
 }
 
+// ---- the same split in two for the fast level kernel (avd_fbfast.hip): the normal-equation wave stops at r2 .. r6 (before
+// the border attenuation), the chain wave -- which has issue slots to spare -- applies the attenuation and forms the five
+// products.  Same operations in the same order as ne_finish2: bit-identical.
+__device__ __forceinline__ void ne_finish_r(const NeIn& in, const NeG2& g, int x, int y, int w, int h, float (&r)[5], bool zf = false)
+{
+    const float dx = zf ? 0.f : in.dx, dy = zf ? 0.f : in.dy;
+    const int x1 = g.x1, y1 = g.y1;
+    const float fx = (x + dx) - x1, fy = (y + dy) - y1;
+    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const float b2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
+    const float b3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
+    const float b4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
+    const float b5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
+    const float b6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
+    float r2 = inside ? b2 : 0.f, r3 = inside ? b3 : 0.f;
+    const float r4 = inside ? (in.r0[2] + b4) * 0.5f : in.r0[2];
+    const float r5 = inside ? (in.r0[3] + b5) * 0.5f : in.r0[3];
+    const float r6 = inside ? (in.r0[4] + b6) * 0.25f : in.r0[4] * 0.5f;
+    r2 = (in.r0[0] - r2) * 0.5f;
+    r3 = (in.r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    r[0] = r2; r[1] = r3; r[2] = r4; r[3] = r5; r[4] = r6;
+}
+
+__device__ __forceinline__ void ne_products(const float (&r)[5], float scale, float (&M)[5])
+{
+    const float r2 = r[0] * scale, r3 = r[1] * scale, r4 = r[2] * scale, r5 = r[3] * scale, r6 = r[4] * scale;
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
 }  // namespace

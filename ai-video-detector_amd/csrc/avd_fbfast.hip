@@ -20,8 +20,9 @@
 // and a pair to one workgroup.  A workgroup owns a STRIP of a pair: OW output columns plus 7 halo columns on each side
 // (recomputed, not exchanged: there is no cross-workgroup dependency inside a launch), all rows.  Columns outside the image
 // clamp to the edge column, which is exactly cv2's replicated border of vsum.  Per 64-column block of the strip four waves:
-//   N0, N1  normal equations (FarnebackUpdateMatrices) of two image rows each per step -> M ring in LDS (float)
-//   C       the literal vertical chain: M rows in, vsum rows (double) out to LDS
+//   N0, N1  normal equations (FarnebackUpdateMatrices up to r2 .. r6) of two image rows each per step -> ring in LDS (float)
+//   C       border attenuation and the five products of M (the N waves are the pole of a step, this wave has issue slots to
+//           spare), then the literal vertical chain: M rows in, vsum rows (double) out to LDS
 //   X       horizontal window sums + 2 x 2 solve + flow stores.  A lane owns FOUR consecutive columns of one row: 18
 //           doubles (nine 16-byte LDS reads) per channel give four windows with 21 additions, and a wave covers 4 rows x 64
 //           columns per step
@@ -115,7 +116,6 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     constexpr int H = W, plane = W * H;
     constexpr int NGS = GD + 1, NIS = 2 * NGS, U = NIS / EPS;   // gather slots, input slots, steps per loop body
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
-    const float sx = border_factor(x, W);
     auto ent = [&](int i) { return 4 * (i / EPS) + EPS * k + (i % EPS); };  // this wave's i-th entry
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
@@ -138,8 +138,8 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
             ne_load(R, flow, r0base, flbase, x, row_of(ent(i + NIS - 1)), W, plane, in[(ii + NIS - 1) % NIS]);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            float a[5];
-            ne_finish2(in[ii % NIS], g[ii % NGS], x, e, W, H, sx, border_factor(e, H), a, zf);
+            float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies
+            ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
             float* dst = mring + (e & 7) * Ge::M_SLOT + lane;
 #pragma unroll
             for (int c = 0; c < 5; c++) dst[c * 64] = a[c];
@@ -168,7 +168,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
 // while the window still touches the top edge) leaves and the vsum row of image row e - 7 is published.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename Ge>
-__device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, int b, int lane)
+__device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, int b, int x, int lane)
 {
     constexpr int W = Ge::W;
     FBF_WAIT_DECL
@@ -176,6 +176,7 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
     const long long fbf_t0 = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int H = W;
+    const float sx = border_factor(x, W);                 // x part of the border attenuation: a per-lane constant
     float ring[16][5];                                   // ring[e & 15] = M row of entry e (statically indexed)
     double vs[5] = {0., 0., 0., 0., 0.};
     double* vdst = vsring + 8 + 64 * b + lane;
@@ -192,9 +193,10 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
                     if (e < Ge::NE) {                                        // wave-uniform
                         const int er = e < H - 1 ? e : H - 1;
                         const float* src = mring + (er & 7) * Ge::M_SLOT + lane;
-                        float a[5];
+                        float rr[5], a[5];
 #pragma unroll
-                        for (int c = 0; c < 5; c++) a[c] = src[c * 64];
+                        for (int c = 0; c < 5; c++) rr[c] = src[c * 64];
+                        ne_products(rr, sx * border_factor(er, H), a);       // FarnebackUpdateMatrices' last lines, moved here from the N waves
                         if (e == 0) {
 #pragma unroll
                             for (int c = 0; c < 5; c++) vs[c] = (double)(a[c] * (float)(kM + 2));
@@ -371,7 +373,7 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
         role_ne<Ge>(R, flow_in, mring, p, x, role, lane, zero_first != 0);
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
-        role_chain<Ge>(mring, vsring, b, lane);
+        role_chain<Ge>(mring, vsring, b, x, lane);
     } else {
         role_solve<Ge>(vsring, flow_out, mag_out, p, b, role - Ge::NPB - 1, lane, o0, width);
     }
