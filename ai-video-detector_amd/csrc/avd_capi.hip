@@ -58,7 +58,7 @@ void free_ws(Workspace& ws, bool keep_weights = false)
     F(ws.d_clipstart);
     if (ws.h_clipstart) (void)hipHostFree(ws.h_clipstart);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); F(ws.d_flow2[k]); }
-    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_part); F(ws.d_rec); F(ws.d_mag);
+    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_rec); F(ws.d_mag);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
     F(ws.d_cnn_w); F(ws.d_cnn_b); F(ws.d_cnn_img); F(ws.d_cnn_pool); F(ws.d_cnn_logits);
@@ -240,7 +240,6 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
             ws.flow_res[k] = nullptr;
         }
         if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
-        if (int e = dev_alloc(ctx, ws.d_part, np * 2 * 16)) return e;
         if (int e = dev_alloc(ctx, ws.d_mag, np * (size_t)AVD_NPIX)) return e;
         if (ws.d_vs) { (void)hipFree(ws.d_vs); ws.d_vs = nullptr; }
         if (ws.d_vs0) { (void)hipFree(ws.d_vs0); ws.d_vs0 = nullptr; }

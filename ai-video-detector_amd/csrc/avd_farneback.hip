@@ -885,73 +885,77 @@ __device__ __forceinline__ float chunk_total(const float* part)
     return t;
 }
 
-// PASS 0: per-buffer pairwise sums of mag.  PASS 1: of (mag - mean)^2, mean = sum/N in float32.
-// grid (kNChunk, npairs); part[pair][pass][kNChunk]
-// MAG: the buffer holds |flow| already (written by the last launch of the fast level kernel) instead of the two flow planes
-template <int PASS, bool MAG = false>
-__global__ __launch_bounds__(256) void k_stats_chunk(const float* __restrict__ flow, float* __restrict__ part)
+// Both statistics of a pair in ONE workgroup of 512 threads, the pair's 102 400 magnitudes in REGISTERS (200 per thread):
+// thread (leaf l = tid / 8, accumulator a = tid % 8) holds, for each of the 13 iterator buffers, the 16 elements
+// l * 128 + a + 8 k that numpy's unrolled leaf loop adds into accumulator a.  A buffer's sum is then: the sequential
+// 16-element sum per thread, the 8-accumulator tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the balanced tree over the
+// buffer's 64 (last buffer: 32) leaves -- shuffles inside a wave (8 leaves), eight per-wave values through LDS.  The
+// second pass, (mag - mean)^2 with mean = sum / N in float32, runs on the registers: the magnitudes are read once.
+// (18.6 us for 119 pairs; a variant with 16-byte loads and the 16-element sum relayed over four lanes took 22.9 us.)
+// mag[pair][N] = |flow|: written by the last launch of the fast level kernel, or by k_mag below from the two flow planes
+__global__ __launch_bounds__(512) void k_stats_pair(const float* __restrict__ mag, float* __restrict__ stats)
 {
-    __shared__ float buf[kChunk];
-    __shared__ float leaf[kChunk / 16];              // 64 leaves x 8 accumulators
-    __shared__ float node[64];
-    const int p = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
-    const int base = ch * kChunk;
-    const int len = min(kChunk, AVD_NPIX - base);
-    const float* fxp = flow + (int64_t)p * (MAG ? 1 : 2) * AVD_NPIX + base;
-    const float* fyp = fxp + AVD_NPIX;
-    float mean32 = 0.f;
-    if (PASS == 1) mean32 = chunk_total(part + (int64_t)p * 2 * kNChunk) / (float)AVD_NPIX;   // _var: f32 true_divide
-    for (int i = tid * 4; i < len; i += 1024) {
-        float4 mg;
-        if (MAG) {
-            mg = *reinterpret_cast<const float4*>(fxp + i);
-        } else {
-            const float4 fx = *reinterpret_cast<const float4*>(fxp + i), fy = *reinterpret_cast<const float4*>(fyp + i);
-            mg.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
-            mg.y = sqrtf(fx.y * fx.y + fy.y * fy.y);
-            mg.z = sqrtf(fx.z * fx.z + fy.z * fy.z);
-            mg.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
-        }
-        if (PASS == 1) {
-            float d;
-            d = mg.x - mean32; mg.x = d * d;
-            d = mg.y - mean32; mg.y = d * d;
-            d = mg.z - mean32; mg.z = d * d;
-            d = mg.w - mean32; mg.w = d * d;
-        }
-        *reinterpret_cast<float4*>(buf + i) = mg;
-    }
-    __syncthreads();
-    const int nleaf = len >> 7;                       // 64 or 32: a power of two
-    for (int it = tid; it < nleaf * 8; it += 256) {
-        const float* q = buf + (it >> 3) * 128 + (it & 7);
-        float r = q[0];
+    __shared__ float wpart[kNChunk][8];
+    __shared__ float ctot[kNChunk];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int l = tid >> 3, wave = tid >> 6;
+    const bool in_last = l < ((AVD_NPIX - (kNChunk - 1) * kChunk) >> 7);          // the last buffer has 32 leaves
+    const float* src = mag + (int64_t)p * AVD_NPIX + l * 128 + (tid & 7);
+    float v[kNChunk][16];
 #pragma unroll
-        for (int k = 1; k < 16; k++) r += q[8 * k];
-        leaf[it] = r;
-    }
-    __syncthreads();
-    if (tid < nleaf) {
-        const float* r = leaf + tid * 8;
-        node[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    }
-    __syncthreads();
-    for (int stride = 1; stride < nleaf; stride <<= 1) {     // balanced pairwise tree over the leaves
-        if (tid < nleaf && (tid % (2 * stride)) == 0) node[tid] = node[tid] + node[tid + stride];
+    for (int c = 0; c < kNChunk; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[c][k] = (c < kNChunk - 1 || in_last) ? src[c * kChunk + 8 * k] : 0.f;
+    float total[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+        for (int c = 0; c < kNChunk; c++) {
+            float r = v[c][0];
+#pragma unroll
+            for (int k = 1; k < 16; k++) r += v[c][k];
+            // lanes whose partner holds no valid subtree compute values nobody reads
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) r = r + __shfl_down(r, d);
+            if ((tid & 63) == 0) wpart[c][wave] = r;
+        }
         __syncthreads();
+        if (tid < kNChunk) {
+            const float* w = wpart[tid];
+            ctot[tid] = tid < kNChunk - 1 ? ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])) : (w[0] + w[1]) + (w[2] + w[3]);
+        }
+        __syncthreads();
+        total[pass] = chunk_total(ctot);
+        if (pass == 0) {
+            const float mean32 = total[0] / (float)AVD_NPIX;                       // _var: f32 true_divide
+#pragma unroll
+            for (int c = 0; c < kNChunk; c++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const float d = v[c][k] - mean32; v[c][k] = d * d; }
+            __syncthreads();                                                       // ctot / wpart are rewritten by the second pass
+        }
     }
-    if (tid == 0) part[((int64_t)p * 2 + PASS) * kNChunk + ch] = node[0];
+    // stats[pair] = { f32(f64(sum)/N), f32(f64(sumsq)/N) }   (_mean / _var final scalar divides)
+    if (tid == 0) {
+        stats[2 * p] = (float)((double)total[0] / (double)AVD_NPIX);
+        stats[2 * p + 1] = (float)((double)total[1] / (double)AVD_NPIX);
+    }
 }
 
-// stats[pair] = { f32(f64(sum)/N), f32(f64(sumsq)/N) }   (_mean / _var final scalar divides)
-__global__ void k_stats_final(const float* __restrict__ part, float* __restrict__ stats, int npairs)
+// mag = np.sqrt(fx * fx + fy * fy) in float32 (video.py:46) from the planar flow [pair][2][N]: the exact-mode level kernels
+// leave the flow only, the fast one writes the magnitudes itself
+__global__ void k_mag(const float* __restrict__ flow, float* __restrict__ mag, int64_t total4)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npairs) return;
-    const float s = chunk_total(part + (int64_t)p * 2 * kNChunk);
-    const float q = chunk_total(part + ((int64_t)p * 2 + 1) * kNChunk);
-    stats[2 * p] = (float)((double)s / (double)AVD_NPIX);
-    stats[2 * p + 1] = (float)((double)q / (double)AVD_NPIX);
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total4) return;
+    const int64_t p = gid / (AVD_NPIX / 4), i = gid - p * (AVD_NPIX / 4);
+    const float4 fx = reinterpret_cast<const float4*>(flow + p * 2 * AVD_NPIX)[i], fy = reinterpret_cast<const float4*>(flow + (p * 2 + 1) * AVD_NPIX)[i];
+    float4 m;
+    m.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
+    m.y = sqrtf(fx.y * fx.y + fy.y * fy.y);
+    m.z = sqrtf(fx.z * fx.z + fy.z * fy.z);
+    m.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
+    reinterpret_cast<float4*>(mag + p * AVD_NPIX)[i] = m;
 }
 
 // planar flow [pair][2][N] -> cv2's interleaved [pair][N][2] (only when the caller asks for the flow)
@@ -975,7 +979,7 @@ struct Seg {
     float* poly[AVD_FB_LEVELS];
     float* flow[AVD_FB_LEVELS];
     double *vs, *vs0;
-    float *stats, *part, *flow_il;
+    float *stats, *flow_il;
     avd_ctx* prof;                       // non-null: record kernel events of the full-resolution blur launches
 };
 
@@ -995,7 +999,6 @@ static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_of
     g.vs = ws.d_vs ? ws.d_vs + (size_t)pair_off * (5 * AVD_NPIX + 512) : nullptr;
     g.vs0 = ws.d_vs0 ? ws.d_vs0 + (size_t)pair_off * 5 * S * 8 : nullptr;
     g.stats = ws.d_stats + (size_t)pair_off * 2;
-    g.part = ws.d_part + (size_t)pair_off * 2 * 16;
     g.flow_il = ws.d_flow_il ? ws.d_flow_il + (size_t)pair_off * AVD_NPIX * 2 : nullptr;
     return g;
 }
@@ -1122,15 +1125,9 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
     const Seg g = make_seg(ctx, stream, frame_off, pair_off);
     const int np = n - 1;
     const float* fl = ctx->ws.flow_res[0] ? ctx->ws.flow_res[0] : g.flow[0];
-    if (ctx->ws.mag_valid && ctx->ws.d_mag) {
-        const float* mg = ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX;
-        hipLaunchKernelGGL((k_stats_chunk<0, true>), dim3(kNChunk, np), dim3(256), 0, stream, mg, g.part);
-        hipLaunchKernelGGL((k_stats_chunk<1, true>), dim3(kNChunk, np), dim3(256), 0, stream, mg, g.part);
-    } else {
-        hipLaunchKernelGGL(k_stats_chunk<0>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
-        hipLaunchKernelGGL(k_stats_chunk<1>, dim3(kNChunk, np), dim3(256), 0, stream, fl, g.part);
-    }
-    hipLaunchKernelGGL(k_stats_final, dim3((np + 63) / 64), dim3(64), 0, stream, (const float*)g.part, g.stats, np);
+    float* mg = ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX;
+    if (!ctx->ws.mag_valid) launch1d(k_mag, (int64_t)np * (AVD_NPIX / 4), 256, stream, fl, mg, (int64_t)np * (AVD_NPIX / 4));
+    hipLaunchKernelGGL(k_stats_pair, dim3(np), dim3(512), 0, stream, (const float*)mg, g.stats);
     if (g.flow_il)
         launch1d(k_flow_interleave, (int64_t)np * AVD_NPIX, 256, stream, fl, g.flow_il, (int64_t)np * AVD_NPIX);
     HIP_TRY(ctx, hipGetLastError());

@@ -124,13 +124,12 @@ struct Workspace {
     float* d_flow[AVD_FB_LEVELS] = {};    // [n-1][2][hL*wL]  planar
     float* d_flow2[AVD_FB_LEVELS] = {};   // second flow buffer of a level: the fast level kernel (avd_fbfast.hip) ping-pongs
     const float* flow_res[AVD_FB_LEVELS] = {};   // where the last call left the final flow of each level (d_flow or d_flow2)
-    float* d_mag = nullptr;               // [n-1][320*320] |flow| of the full-resolution level (written by the fast level kernel)
+    float* d_mag = nullptr;               // [n-1][320*320] |flow| of the full-resolution level (written by the fast level kernel, or by k_mag in exact mode)
     int mag_valid = 0;                    // d_mag holds the magnitudes of the chunk being processed
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
     float* d_stats = nullptr;             // [n-1][2] mean, var
-    float* d_part = nullptr;              // [n-1][2][13] per-buffer partial sums (numpy reduction order)
     avd_frame_record* d_rec = nullptr;    // [n]
     avd_frame_record* h_rec = nullptr;    // [n] pinned landing buffer of the asynchronous copy-out
     // ViT patch-embed extension (avd_vit.hip): weights [768][768] bf16 + bias, im2col patches, token staging
