@@ -1075,6 +1075,8 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         if (k == AVD_FB_LEVELS - 1) {
             // the coarsest level starts from zero flow: the fused kernel is told so, the two-kernel path reads a cleared buffer
             if (!((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
+        } else if (k == 0 && ctx->fb_mode == 1 && ctx->fb_fold_up) {
+            // fast mode, 320 px: the first launch of the level resizes the previous level's flow on the fly (avd_fbfast.hip, UP)
         } else {
             const int items = np * 2 * h * (w / 4);
             const float* prev = ctx->ws.flow_res[k + 1];
@@ -1088,9 +1090,11 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             float* a = g.flow[k];
             float* b = ctx->ws.d_flow2[k] + (size_t)pair_off * 2 * plane;
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
+            const bool up = k == 0 && ctx->fb_fold_up;
             for (int it = 0; it < 3; it++) {
                 float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
-                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], a, b, mag, np, k == AVD_FB_LEVELS - 1 && it == 0)) return e;
+                const float* in = (up && it == 0) ? ctx->ws.flow_res[k + 1] : a;
+                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], in, b, mag, np, k == AVD_FB_LEVELS - 1 && it == 0, up && it == 0)) return e;
                 float* t = a; a = b; b = t;
             }
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);

@@ -60,6 +60,14 @@ __device__ __forceinline__ void ne_load(const float* __restrict__ R, const float
     in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off<float>(R, pb + 16u);
 }
 
+// the R0 part alone (the flow comes from elsewhere)
+__device__ __forceinline__ void ne_load_r0(const float* __restrict__ R, unsigned r0base, int x, int y, int w, NeIn& in)
+{
+    const unsigned pb = (r0base + (unsigned)(y * w + x) * 5u) * 4u;
+    const F4 v = ld_off<F4>(R, pb);
+    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off<float>(R, pb + 16u);
+}
+
 // gather the four bilinear neighbours of the warped position (clamped address when outside:
 // the values are discarded by ne_finish, exactly as cv2 takes the "else" branch there)
 __device__ __forceinline__ void ne_gather(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,

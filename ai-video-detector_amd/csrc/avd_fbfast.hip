@@ -72,7 +72,11 @@ struct FGeo {
     static constexpr int M_SLOT = 5 * 64;            // floats of one row of one block
     static constexpr int M_FLOATS = NB * 8 * M_SLOT; // ring of 8 rows per block
     static constexpr int LDS_DOUBLES = VS_DOUBLES + M_FLOATS / 2;
-    static_assert(LDS_DOUBLES * 8 <= 163840 && NWAVES <= 16, "LDS layout, workgroup size");
+    // first iteration of a level below the coarsest (UP): the chain wave forms the level's initial flow -- the previous level's
+    // flow resized x 2 -- a few rows ahead of the N waves, in a ring of 16 rows x 2 components per block
+    static constexpr int F_SLOT = 2 * 64;            // floats of one row of one block
+    static constexpr int F_FLOATS = NB * 16 * F_SLOT;
+    static_assert((LDS_DOUBLES + F_FLOATS / 2) * 8 <= 163840 && NWAVES <= 16, "LDS layout, workgroup size");
     static_assert(H % 4 == 0 && (NPB == 2 || NPB == 4) && (XPB == 1 || XPB == 2), "whole groups of image rows");
 };
 
@@ -104,9 +108,11 @@ __device__ __forceinline__ void fb_barrier() { __syncthreads(); }
 // GD = entries of lead of the bilinear gather of R1 (its address needs the flow, so it cannot be issued arbitrarily early):
 // the gather of entry i + GD is issued while entry i is evaluated, the inputs (flow, R0) of entry i + 2 GD + 1 likewise.
 // Slots are statically indexed: the loop body is GD + 1 steps = 2 (GD + 1) entries.
-template <typename Ge>
+// UP: the flow of this launch is the previous level's, resized: the chain wave leaves row y of it in fring[y & 15] at least
+// one step before it is wanted here (see role_chain); it is fetched from there one entry before the gather that needs it.
+template <typename Ge, bool UP>
 __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
-                                        int p, int x, int k, int lane, bool zf)
+                                        const float* __restrict__ fring, int p, int x, int k, int lane, bool zf)
 {
     constexpr int W = Ge::W, GD = Ge::GD, EPS = Ge::EPS;
     FBF_WAIT_DECL
@@ -120,8 +126,18 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
     NeG2 g[NGS];
+    auto flow_of = [&](int row, NeIn& s) { const float* f = fring + (row & 15) * Ge::F_SLOT + lane; s.dx = f[0]; s.dy = f[64]; };
+    auto load_in = [&](int row, NeIn& s) {
+        if (UP) ne_load_r0(R, r0base, x, row, W, s);
+        else ne_load(R, flow, r0base, flbase, x, row, W, plane, s);
+    };
+    if (UP) fb_barrier();                                  // the chain wave has filled rows 0 .. 11 of the flow ring
 #pragma unroll
-    for (int i = 0; i < NIS - 1; i++) ne_load(R, flow, r0base, flbase, x, row_of(ent(i)), W, plane, in[i]);
+    for (int i = 0; i < NIS - 1; i++) load_in(row_of(ent(i)), in[i]);
+    if (UP) {
+#pragma unroll
+        for (int i = 0; i <= GD; i++) flow_of(row_of(ent(i)), in[i]);
+    }
 #pragma unroll
     for (int i = 0; i < GD; i++) ne_gather2(R, r1base, in[i], x, row_of(ent(i)), W, H, g[i], zf);
     auto work = [&](int t, int q) __attribute__((always_inline)) {
@@ -135,8 +151,9 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
             ne_gather2(R, r1base, in[(ii + GD) % NIS], x, row_of(ent(i + GD)), W, H, g[(ii + GD) % NGS], zf);
 #endif
 #ifndef AVD_FBF_NOINLOAD
-            ne_load(R, flow, r0base, flbase, x, row_of(ent(i + NIS - 1)), W, plane, in[(ii + NIS - 1) % NIS]);
+            load_in(row_of(ent(i + NIS - 1)), in[(ii + NIS - 1) % NIS]);
 #endif
+            if (UP) flow_of(row_of(ent(i + GD + 1)), in[(ii + GD + 1) % NIS]);   // for the gather issued with the next entry
             __builtin_amdgcn_sched_barrier(0);
             float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies
             ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
@@ -167,8 +184,58 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
 // C: cv2's vertical running sums, literally.  Entry e brings image row min(e, H-1) in; from e = 7 on, row e - 15 (row 0
 // while the window still touches the top edge) leaves and the vsum row of image row e - 7 is published.
 // ------------------------------------------------------------------------------------------------------------------
+// UP: the same wave (it has issue slots and registers to spare) also forms the launch's input flow, cv2's
+// resize(prev_flow, INTER_LINEAR) * 2 as k_flow_up (avd_farneback.hip) computes it: source coordinate d / 2 - 0.25, weights
+// 0.25 / 0.75, the first column with weights (1, 0), the last one copied.  Group g = rows 4g .. 4g+3 needs the four coarse
+// rows 2g-1 .. 2g+2 (clamped); it is written during step g - 3 (groups 0 .. 2 before the first step), read by the N waves
+// from step g - 2 on, and its ring slot is reused four steps later.
 template <typename Ge>
-__device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, int b, int x, int lane)
+struct UpRows { F2 v[4][2]; };
+
+template <typename Ge>
+__device__ __forceinline__ void up_issue(const float* __restrict__ prev, unsigned pbase, int g, int x, UpRows<Ge>& u)
+{
+    constexpr int PW = Ge::W / 2, PH = Ge::H / 2;
+    const int sx = x == 0 ? 0 : (x - 1) >> 1;            // floor(x / 2 - 0.25), the first column snapped to 0
+    const int xs = sx < PW - 2 ? sx : PW - 2;            // an 8-byte load never leaves the row
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int r = 2 * g - 1 + q;
+        r = r < 0 ? 0 : (r > PH - 1 ? PH - 1 : r);
+#pragma unroll
+        for (int c = 0; c < 2; c++) u.v[q][c] = ld_off<F2>(prev, (pbase + (unsigned)(c * PW * PH + r * PW + xs)) * 4u);
+    }
+}
+
+template <typename Ge>
+__device__ __forceinline__ void up_finish(float* __restrict__ fring, int g, int x, int lane, const UpRows<Ge>& u)
+{
+    constexpr int W = Ge::W, PW = W / 2;
+    const int sx = x == 0 ? 0 : (x - 1) >> 1;
+    const bool edge = sx + 1 >= PW;                      // the last column: the value is copied, no weights
+    const float a1 = x == 0 ? 0.f : ((x & 1) ? 0.25f : 0.75f), a0 = 1.f - a1;
+    float d[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float lo = sx > PW - 2 ? u.v[q][c].b : u.v[q][c].a, hi = u.v[q][c].b;
+            d[q][c] = edge ? lo * 1.f : lo * a0 + hi * a1;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int y = 4 * g + j;                          // < H: only whole groups of image rows are formed
+        const int q0 = j == 0 ? 0 : (j == 3 ? 2 : 1);     // floor(y / 2 - 0.25) - (2g - 1)
+        const float b1 = (j & 1) ? 0.25f : 0.75f, b0 = 1.f - b1;
+        float* dst = fring + (y & 15) * Ge::F_SLOT + lane;
+#pragma unroll
+        for (int c = 0; c < 2; c++) dst[c * 64] = (d[q0][c] * b0 + d[q0 + 1][c] * b1) * 2.f;
+    }
+}
+
+template <typename Ge, bool UP>
+__device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, float* __restrict__ fring,
+                                           const float* __restrict__ prev, int p, int b, int x, int lane)
 {
     constexpr int W = Ge::W;
     FBF_WAIT_DECL
@@ -180,11 +247,20 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
     float ring[16][5];                                   // ring[e & 15] = M row of entry e (statically indexed)
     double vs[5] = {0., 0., 0., 0., 0.};
     double* vdst = vsring + 8 + 64 * b + lane;
+    const unsigned pbase = (unsigned)p * 2u * (W / 2) * (H / 2);
+    UpRows<Ge> up;
+    if (UP) {
+#pragma unroll
+        for (int g = 0; g < 3; g++) { up_issue<Ge>(prev, pbase, g, x, up); up_finish<Ge>(fring, g, x, lane, up); }
+        fb_barrier();
+    }
     for (int t4 = 0; t4 < Ge::T; t4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int t = t4 + q;
             fb_barrier();
+            const bool up_now = UP && 4 * (t + 3) < H;                       // wave-uniform
+            if (up_now) up_issue<Ge>(prev, pbase, t + 3, x, up);             // consumed after the chain work of this step
             if (t >= 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -219,6 +295,7 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
                     }
                 }
             }
+            if (up_now) up_finish<Ge>(fring, t + 3, x, lane, up);
         }
     }
     FBF_WAIT_OUT(threadIdx.x >> 6, 2, fbf_t0)
@@ -249,7 +326,7 @@ __device__ __forceinline__ double recip_exact(double d)
 // chunk of four output columns).  The strip's lane column u holds image column clamp(xlo + u) with xlo = o0 - 7, and vsum
 // of lane column u sits at index u + 8 of its line: the window of output column o0 + i is lane columns i .. i + 14.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename Ge>
+template <typename Ge, bool UP>
 __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, float* __restrict__ mag_out,
                                            int p, int b, int xi, int lane, int o0, int ow)
 {
@@ -263,6 +340,7 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
     const bool colok = CPL * j < ow;
     float* fl = flow_out + (size_t)p * 2 * plane + o0 + CPL * j;
     const double* vsrc = vsring + 8 + CPL * j;
+    if (UP) fb_barrier();                                  // the chain wave's fill of the flow ring
     for (int t4 = 0; t4 < Ge::T; t4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -334,13 +412,14 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
     FBF_WAIT_OUT(threadIdx.x >> 6, 3, fbf_t0)
 }
 
-template <typename Ge>
+// UP: flow_in is the PREVIOUS level's flow ([pair][2][H/2][W/2]); the launch's input flow is that, resized x 2 and doubled
+template <typename Ge, bool UP>
 __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
                                                               float* __restrict__ flow_out, float* __restrict__ mag_out, int npairs,
                                                               int nstrips, int ow, int zero_first, int dbg)
 {
     constexpr int W = Ge::W, NB = Ge::NB;
-    __shared__ __align__(16) double lds[Ge::LDS_DOUBLES];
+    __shared__ __align__(16) double lds[Ge::LDS_DOUBLES + (UP ? Ge::F_FLOATS / 2 : 0)];
     double* vsring = lds;
     float* mrings = reinterpret_cast<float*>(lds + Ge::VS_DOUBLES);
     const int lane = threadIdx.x & 63;
@@ -369,22 +448,28 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     const int xu = o0 - kM + 64 * b + lane;               // image column of this lane (clamped: replicated border)
     const int x = xu < 0 ? 0 : (xu > W - 1 ? W - 1 : xu);
     float* mring = mrings + b * 8 * Ge::M_SLOT;
+    float* fring = reinterpret_cast<float*>(lds + Ge::LDS_DOUBLES) + b * 16 * Ge::F_SLOT;   // UP only
     if (role < Ge::NPB) {
-        role_ne<Ge>(R, flow_in, mring, p, x, role, lane, zero_first != 0);
+        role_ne<Ge, UP>(R, flow_in, mring, fring, p, x, role, lane, zero_first != 0);
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
-        role_chain<Ge>(mring, vsring, b, x, lane);
+        role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane);
     } else {
-        role_solve<Ge>(vsring, flow_out, mag_out, p, b, role - Ge::NPB - 1, lane, o0, width);
+        role_solve<Ge, UP>(vsring, flow_out, mag_out, p, b, role - Ge::NPB - 1, lane, o0, width);
     }
 }
 
 template <typename Ge>
-void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* mag, int np, int nstrips, int ow, int zero_first)
+void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* mag, int np, int nstrips, int ow, int zero_first, int up)
 {
     const int grid = 8 * ((np + 7) / 8) * nstrips;
     static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
-    hipLaunchKernelGGL((k_fb_fast<Ge>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, np, nstrips, ow, zero_first, dbg);
+    // the folded resize only exists where it pays: at 320 px it costs the launch 3.5 us and saves k_flow_up's 37; the small
+    // levels are latency-bound on exactly the chain wave that would do it (160 px: 45 -> 84 us per launch against 12 saved)
+    if constexpr (Ge::W == 320) {
+        if (up) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, np, nstrips, ow, 0, dbg); return; }
+    }
+    hipLaunchKernelGGL((k_fb_fast<Ge, false>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, np, nstrips, ow, zero_first, dbg);
 }
 
 }  // namespace
@@ -392,25 +477,28 @@ void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fo
 // ONE blur iteration of one pyramid level for `np` pairs: flow_in -> flow_out (different buffers), R = polynomial expansions
 // of np + 1 frames ([frame][y][x][5]), flows planar [pair][2][y][x]
 // mag_out (320-px level, last iteration; else null): float[pair][320][320] receives |flow|
+// up: flow_in is the previous (coarser) level's final flow, [pair][2][w/2][w/2]: the kernel forms this level's initial flow
+// from it on the fly (cv2: resize x 2, INTER_LINEAR, times 2) instead of reading one a separate launch wrote
 int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int np,
-                   int zero_first)
+                   int zero_first, int up)
 {
     if (np <= 0) return 0;
+    if (up && w != 320) { ctx->err = "launch_fb_fast: the folded resize of the previous flow exists at 320 px only"; return AVD_ERR_ARG; }
     if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
-    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 160, zero_first); break;
+    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 160, zero_first, up); break;
     case 160:
-        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first);
-        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first);
+        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first, up);
+        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first, up);
         break;
     case 80:
-        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first);
-        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first);
+        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first, up);
+        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first, up);
         break;
     case 40:
-        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first);
-        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first);
+        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first, up);
+        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first, up);
         break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
     }

@@ -171,6 +171,7 @@ struct avd_ctx {
     void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
     int cnn_tiles = 0;              // convolution tiling of the CNN extension: 0 = heuristic, 1 = 256-pixel tiles, 2 = 128 x 128 wherever possible
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
+    int fb_fold_up = 1;             // fast mode: the first launch of the 320-px level forms its initial flow from the 160-px level's (no k_flow_up<320> launch); AVD_FB_FOLD_UP=0 = A/B
     int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
                                     // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
 };
@@ -230,7 +231,7 @@ int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, flo
 // avd_fbfast.hip: ONE blur iteration of one pyramid level, a pair spread over several workgroups (column strips), the
 // horizontal window sums formed directly in double (the vertical chain stays literal); flow_in != flow_out
 int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int np,
-                   int zero_first);
+                   int zero_first, int up);
 // avd_norm.hip (extensions): LayerNorm over rows of 256..2048 values, softmax over rows of logits; device pointers
 int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps);
 int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols);

@@ -260,6 +260,8 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * the exact kernels' bit for bit on well-posed inputs and stays within 1e-5 px / ai_susp within 1e-6 otherwise, except on
  * chaotic pairs where the reference result itself moves by more under a 1-ulp perturbation, tests/test_gpu_fbfast.py);
  * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
+ * "fb_fold_up" (fast mode, default 1, environment AVD_FB_FOLD_UP; no effect on results): the first launch of the 320-px level
+ * resizes the 160-px level's flow itself instead of reading the output of a separate resize launch.
  * "fb_fused" (exact mode only, no effect on results): bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
  * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
  * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM.  "cnn_tiles": tiling of the
