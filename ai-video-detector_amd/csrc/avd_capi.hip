@@ -257,31 +257,42 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
 }
 
 // ---- record assembly -------------------------------------------------------------------
-// clipstart[f] != 0: frame f is the first of its clip -- it has no predecessor (flow 0, like frame 0 of a single clip;
-// the pair (f - 1, f) the Farneback stage computed across the clip boundary is ignored)
-__global__ void k_records(const unsigned long long* lap, const int* ham, const float* stats, int stats_off,
-                          avd_frame_record* rec, int f0, int count, int write_pre, int write_flow, const int* clipstart)
+// One workgroup per frame, ONE launch per Farneback chunk (it follows the flow statistics): the frame's Laplacian moments,
+// its Hamming distance to the previous frame (video.py:8: the 1024 aHash bits, one per byte, of both frames) and the
+// statistics of pair (f - 1, f).  The first frame of a clip has no predecessor (ham = -1, flow 0; the pair the Farneback stage
+// computed across a clip boundary is ignored): f == 0, or clipstart[f] != 0 when the call holds several clips
+// (clipstart == nullptr: one clip).  with_flow == 0: a call without any pair (one frame).
+__global__ __launch_bounds__(256) void k_records(const unsigned long long* __restrict__ lap, const uint8_t* __restrict__ bits,
+                                                const float* __restrict__ stats, int stats_off, avd_frame_record* __restrict__ rec,
+                                                int f0, const int* __restrict__ clipstart, int with_flow)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int f = f0 + i;
-    const bool first = f == 0 || clipstart[f] != 0;
-    if (write_pre) {
-        rec[f].lap_sum = (int64_t)lap[2 * f];
-        rec[f].lap_sumsq = (int64_t)lap[2 * f + 1];
-        rec[f].ham = ham[f];
-        rec[f].reserved = 0;
-        if (first) { rec[f].flow_mean = 0.f; rec[f].flow_var = 0.f; }
+    __shared__ int wsum[4];
+    const int f = f0 + blockIdx.x, tid = threadIdx.x;
+    const bool first = f == 0 || (clipstart && clipstart[f] != 0);
+    int c = 0;
+    if (!first) {
+        const unsigned a = reinterpret_cast<const unsigned*>(bits + (int64_t)f * 1024)[tid];
+        const unsigned b = reinterpret_cast<const unsigned*>(bits + (int64_t)(f - 1) * 1024)[tid];
+        c = __popc(a ^ b);
     }
-    if (write_flow && !first) {
-        rec[f].flow_mean = stats[2 * (f - 1 - stats_off)];
-        rec[f].flow_var = stats[2 * (f - 1 - stats_off) + 1];
-    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if ((tid & 63) == 0) wsum[tid >> 6] = c;
+    __syncthreads();
+    if (tid != 0) return;
+    avd_frame_record r;
+    r.lap_sum = (int64_t)lap[2 * f];
+    r.lap_sumsq = (int64_t)lap[2 * f + 1];
+    r.ham = first ? -1 : wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    r.reserved = 0;
+    r.flow_mean = (first || !with_flow) ? 0.f : stats[2 * (f - 1 - stats_off)];
+    r.flow_var = (first || !with_flow) ? 0.f : stats[2 * (f - 1 - stats_off) + 1];
+    rec[f] = r;
 }
 
 // Farneback + stats over all n-1 pairs in chunks; pair p = (frame p, frame p+1).
 static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h_mean, float* h_var,
-                           float* h_flow_out, bool into_records)
+                           float* h_flow_out, bool into_records, const int* records_clipstart = nullptr)
 {
     Workspace& ws = ctx->ws;
     if (n < 2) return 0;
@@ -300,9 +311,10 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
         rc = launch_flow_stats(ctx, ctx->stream, np + 1, 0, 0);
         if (rc) break;
         if (into_records) {
-            hipLaunchKernelGGL(k_records, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
-                               (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats,
-                               p0, ws.d_rec, p0 + 1, np, 0, 1, (const int*)ws.d_clipstart);
+            // frames p0 + 1 .. p0 + np, and frame 0 with the first chunk
+            const int fa = p0 == 0 ? 0 : p0 + 1;
+            hipLaunchKernelGGL(k_records, dim3(p0 + np + 1 - fa), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap,
+                               (const uint8_t*)ws.d_hash, (const float*)ws.d_stats, p0, ws.d_rec, fa, records_clipstart, 1);
         }
         if (h_mean || h_var || h_flow_out) {
             std::vector<float> st((size_t)np * 2);
@@ -557,19 +569,23 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
             build_yuv_consts(nv.k);
             if (int e = launch_preprocess_nv12(ctx, d_in, nv, k.n, k.h, k.w, k.row_stride, k.frame_stride)) return e;
         }
-        if (int e = launch_hash(ctx, k.n)) return e;
+        if (int e = launch_hash(ctx, k.n, false)) return e;
         f0 += k.n;
         rb += rowbuf_elems_for(ws, k.n);
         lp += lappart_elems_for(ws, k.n);
     }
     ws.f0 = 0; ws.rowbuf_off = 0; ws.lappart_off = 0;
     stage_mark(ctx, 1);
-    HIP_TRY(ctx, hipMemcpyAsync(ws.d_clipstart, ws.h_clipstart, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_records, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const unsigned long long*)ws.d_lap, (const int*)ws.d_ham, (const float*)ws.d_stats, 0,
-                       ws.d_rec, 0, n, 1, 0, (const int*)ws.d_clipstart);
+    const int* clipstart = nullptr;                        // one clip: frame 0 is the only one without a predecessor
+    if (nclips > 1) {
+        HIP_TRY(ctx, hipMemcpyAsync(ws.d_clipstart, ws.h_clipstart, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+        clipstart = ws.d_clipstart;
+    }
     stage_mark(ctx, 2);
-    if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true)) return e;
+    if (n < 2)
+        hipLaunchKernelGGL(k_records, dim3(n), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap, (const uint8_t*)ws.d_hash,
+                           (const float*)nullptr, 0, ws.d_rec, 0, clipstart, 0);
+    else if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true, clipstart)) return e;
     stage_mark(ctx, 3);
     // into PINNED memory: a device-to-host copy into the caller's pageable buffer would block this thread until
     // the whole call is done and it would not be asynchronous at all; avd_synchronize hands the records over

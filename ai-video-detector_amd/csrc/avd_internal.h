@@ -200,7 +200,7 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
 // NV12 input: Y plane rows at d_y + f*frame_stride + y*row_stride, chroma rows at nv.uv + f*uv_frame_stride + (y/2)*uv_row_stride
 int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& nv, int n, int h, int w,
                            int64_t row_stride, int64_t frame_stride);
-int launch_hash(avd_ctx* ctx, int n);
+int launch_hash(avd_ctx* ctx, int n, bool with_hamming = true);
 int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off);
 int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);
 // avd_vit.hip (extension): patchify + bf16 MFMA GEMM; all pointers device

@@ -773,7 +773,8 @@ int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& n
     return 0;
 }
 
-int launch_hash(avd_ctx* ctx, int n)
+// with_hamming = false: the caller forms the Hamming distances itself (k_records of the analyze entries does, from the bits)
+int launch_hash(avd_ctx* ctx, int n, bool with_hamming)
 {
     Workspace& ws = ctx->ws;
     // the clip's slice of the call's buffers: frame ws.f0 onwards (the first frame of a clip has no predecessor: ham = -1)
@@ -781,7 +782,7 @@ int launch_hash(avd_ctx* ctx, int n)
     hipLaunchKernelGGL(k_hash, dim3(n), dim3(1024), 0, ctx->stream, ws.d_rowbuf + ws.rowbuf_off, ws.hsh, ws.d_area + f0 * 1024,
                        ws.d_hash + f0 * 1024, (const long long*)(ws.d_lap_part + ws.lappart_off), ws.pre.nbands, ws.lap_waves,
                        ws.d_lap + 2 * f0);
-    hipLaunchKernelGGL(k_hamming, dim3(n), dim3(256), 0, ctx->stream, ws.d_hash + f0 * 1024, ws.d_ham + f0);
+    if (with_hamming) hipLaunchKernelGGL(k_hamming, dim3(n), dim3(256), 0, ctx->stream, ws.d_hash + f0 * 1024, ws.d_ham + f0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

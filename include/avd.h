@@ -247,9 +247,10 @@ int avd_release_workspace(avd_ctx* ctx);
 int avd_timer_start(avd_ctx* ctx);
 int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms);
 /* Per-stage device time (ms, HIP events on ctx's stream) of the LAST avd_analyze_frames*
- * call when profiling was enabled with avd_set_profiling(ctx, 1): stage 0 = fused
- * preprocess kernel (+ the 2 KB moment memset), 1 = hash / Hamming / record kernels,
- * 2 = Farneback (pyramid .. flow) + flow statistics, 3 = records copy-out; 4 = duration of the fused level kernel at
+ * call when profiling was enabled with avd_set_profiling(ctx, 1): stage 0 = staging copies, fused
+ * preprocess kernel (+ the 2 KB moment memset) and aHash kernel of every clip of the call, 1 = upload of the clip-start
+ * table (calls with several clips; otherwise empty), 2 = Farneback (pyramid .. flow) + flow statistics + the record kernel
+ * (Hamming distances, record assembly), 3 = records copy-out; 4 = duration of the fused level kernel at
  * 320x320 (all iterations of pyramid level 0 in one launch, events around the launch; with the two-kernel path selected
  * by AVD_FB_FUSED: mean duration of one k_uv launch), 5 = mean duration of one k_hscan<320> launch (two-kernel path only,
  * otherwise 0). */
