@@ -107,6 +107,10 @@ def roofline_objects(n, h, w, stage, latency_ms, mode="fast", ops=None):
     launches = 1 if exact else 3
     fb_ms = lvl_ms / launches                                   # average duration of ONE launch
     alg = fused_level_bytes(n, 3 if exact else 1)
+    if not exact:
+        # the first of the three launches reads the 160-px level's flow (a quarter of the bytes) and resizes it itself
+        # (no k_flow_up<320> launch): mean over the three launches, which is what avg_launch_ms and traffic are
+        alg = (3 * alg - pairs * (320 * 320 - 160 * 160) * 8) // 3
     ach = alg / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0
     lvl_ops = (ops or {}).get("level0_three_iterations_per_pair")
     valu = None
@@ -133,7 +137,8 @@ def roofline_objects(n, h, w, stage, latency_ms, mode="fast", ops=None):
                       "12 waves; literal vertical running sums, horizontal 15-column windows summed directly in double, 2x2 solve)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "bound_note": "per iteration every frame's polynomial expansion (20 B/px) and every pair's flow in + out (16 B/px) cross HBM: "
-                          "441 MB per launch at 119 pairs; PMC traffic 1.2x that (halo columns, partial lines).  Below the achievable "
+                          "441 MB per launch at 119 pairs (the first launch reads the coarser level's flow instead: 368 MB; mean 417 MB); "
+                          "PMC traffic ~1.1x that (halo columns, partial lines, |flow| written by the last launch).  Below the achievable "
                           "~6.3 TB/s the remaining limiter is the texture-addresser / L1 path of the bilinear gathers and the per-step "
                           "workgroup barrier (profiles/r03_experiments.md)"}
     dominant.update({

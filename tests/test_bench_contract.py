@@ -43,7 +43,10 @@ def test_roofline_objects():
         assert abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-3
         assert k["traffic"] is None or k["traffic"] >= 0.9 * k["algorithmic_bytes_per_launch"]   # algorithmic <= measured
     assert dom["launches_per_step"] == 3 and abs(dom["avg_launch_ms"] - 0.15) < 1e-9
-    assert abs(dom["achieved"] - per_iter / 0.15e-3 / 1e9) < 1.0
+    # the first launch reads the 160-px level's flow (and resizes it itself) instead of a 320-px one: mean of the three launches
+    mean_launch = (3 * per_iter - 119 * (320 * 320 - 160 * 160) * 8) // 3
+    assert dom["algorithmic_bytes_per_launch"] == mean_launch < per_iter
+    assert abs(dom["achieved"] - mean_launch / 0.15e-3 / 1e9) < 1.0
     assert abs(pre["achieved"] - 120 * 6_324_240 / 0.158e-3 / 1e9) < 1.0
     assert "k_fb_fast<320>" in dom["kernel"] and 0 < dom["share_of_step"] < 1
     assert dom["valu"]["f32_ops_per_level"] == 119 * 30_000_000 and 0 < dom["valu"]["frac_of_vector_peak"] < 1

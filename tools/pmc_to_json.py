@@ -36,9 +36,12 @@ res = {"label": label, "note": "mean per launch; FETCH_SIZE / WRITE_SIZE in KiB,
 # short names bench.py looks up
 for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_fb_fast<320>", r"k_fb_fast<(FGeo<)?320"), ("k_preprocess_vec", r"k_preprocess_vec"),
                    ("k_preprocess_nv12", r"k_preprocess_nv12")):
-    for name, k in kernels.items():
-        if re.search(pat, name) and "hbm_bytes" in k:
-            res[short] = {"hbm_bytes": k["hbm_bytes"], "kernel": name}
+    # several instantiations of one kernel (k_fb_fast<320, UP = false / true>): the launch-weighted mean over all of them
+    hit = [(name, k) for name, k in kernels.items() if re.search(pat, name) and "hbm_bytes" in k]
+    if hit:
+        nl = sum(k["launches"] for _, k in hit)
+        res[short] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for _, k in hit) / nl, "kernel": " + ".join(n for n, _ in hit),
+                      "launches": nl}
 fb = [k for n, k in kernels.items() if re.search(r"k_fb_level|k_fb_fast|k_pyramid|k_polyexp|k_flow_up|k_stats|k_uv|k_hscan", n) and "hbm_bytes" in k]
 if fb:
     # per clip: launches per clip = launches / clips in the trace; every kernel above is launched a fixed number of times per clip
