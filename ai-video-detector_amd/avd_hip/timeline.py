@@ -28,10 +28,8 @@ def texture_variance(lap_sum, lap_sumsq, npix) -> np.ndarray:
     var = (n*Sxx - Sx^2) / n^2, evaluated in exact integer arithmetic and rounded once.
     Agrees with ``cv2.Laplacian(gray, cv2.CV_64F).var()`` (video.py:52) to ~1e-15 relative."""
     n = int(npix)
-    out = np.empty(len(lap_sum), np.float64)
-    for i, (s, q) in enumerate(zip(lap_sum.tolist(), lap_sumsq.tolist())):
-        out[i] = (n * q - s * s) / (n * n)
-    return out
+    nn = n * n
+    return np.array([(n * q - s * s) / nn for s, q in zip(lap_sum.tolist(), lap_sumsq.tolist())], np.float64)
 
 
 def suspicion(tex: np.ndarray, mot: np.ndarray) -> np.ndarray:
@@ -51,7 +49,7 @@ def records_to_result(rec: np.ndarray, npix: int, w, h, fps, duration) -> dict:
         flow_means = rec["flow_mean"][1:].astype(np.float64)     # float(np.float32) is exact
         flow_vars = rec["flow_var"][1:].astype(np.float64)
         mot = np.concatenate(([0.0], flow_means))                # first frame: no motion term yet
-        timeline = [float(v) for v in suspicion(tex, mot)]
+        timeline = suspicion(tex, mot).tolist()                  # Python floats, as float(v) per element gives
         dup = int(np.count_nonzero(rec["ham"][1:] == 0))
     else:
         tex = flow_means = flow_vars = np.empty(0, np.float64)
