@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------------------
 struct PolyPtrs { const float* I[AVD_FB_LEVELS]; float* R[AVD_FB_LEVELS]; };
 
-constexpr int kPolyRows = 8;                             // image rows per workgroup of the full-resolution scale
+constexpr int kPolyRows = 16;                            // image rows per workgroup of the full-resolution scale
 
 // The 320-px scale (three quarters of the stage's pixels): a workgroup walks kPolyRows consecutive rows.  A lane keeps the
 // eleven rows of its column that the vertical pass reads in registers and slides them (one new load per row instead of
