@@ -40,16 +40,19 @@ struct PyrGeo {
     static constexpr int WL = S >> K;
     static constexpr int NC = K == 0 ? S : 2 * WL;              // filtered columns per row
     static constexpr int OFF = K == 0 ? 0 : (1 << K) / 2 - 1;
-    static constexpr int TR = 8;                                // output rows per workgroup
+    // output rows per workgroup: four at the two coarse scales -- their long filters need (TR - 1) 2^K + 2 + 2 HALF source rows,
+    // and the 40-px scale's 76 rows (50 KB of LDS for every workgroup of the launch) held a CU to three workgroups
+    static constexpr int TR = K >= 2 ? 4 : 8;                   // (2 / 4 / 4 / 8 rows -- 22 KB, seven workgroups per CU -- is slower: 57 vs 52 us)
+    static constexpr int TILES = WL / TR;                       // workgroups per frame
     static constexpr int KS = K == 3 ? 19 : (K == 2 ? 9 : 3), HALF = KS / 2;
     static constexpr int SROWS = K == 0 ? TR + 2 * HALF : ((TR - 1) << K) + 2 + 2 * HALF;   // source rows needed
     static constexpr int PADX = 12, PS = S + 2 * PADX;          // source rows carry their reflected borders (HALF <= 9 < PADX, PADX % 4 == 0)
     static constexpr int SRC_BYTES = SROWS * PS, LDS_BYTES = SRC_BYTES + SROWS * NC * 4;
 };
-constexpr int kPyrLds = PyrGeo<3>::LDS_BYTES > PyrGeo<2>::LDS_BYTES ? PyrGeo<3>::LDS_BYTES : PyrGeo<2>::LDS_BYTES;
-static_assert(kPyrLds >= PyrGeo<1>::LDS_BYTES && kPyrLds >= PyrGeo<0>::LDS_BYTES, "the coarse scales need the most LDS");
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int kPyrLds = cmax(cmax(PyrGeo<3>::LDS_BYTES, PyrGeo<2>::LDS_BYTES), cmax(PyrGeo<1>::LDS_BYTES, PyrGeo<0>::LDS_BYTES));   // 29 KB
 
-// blk = frame * (WL / 8) + tile of this scale
+// blk = frame * TILES + tile of this scale
 template <int K>
 __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* __restrict__ small, const FbConsts* __restrict__ C,
                                              float* __restrict__ I)
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
                                                     float* __restrict__ I3)
 {
     __shared__ __align__(16) char lds[kPyrLds];
-    const int n3 = n * (PyrGeo<3>::WL / 8), n2 = n * (PyrGeo<2>::WL / 8), n1 = n * (PyrGeo<1>::WL / 8);
+    const int n3 = n * PyrGeo<3>::TILES, n2 = n * PyrGeo<2>::TILES, n1 = n * PyrGeo<1>::TILES;
     int b = blockIdx.x;
     if (b < n3) { pyramid_body<3>(lds, b, small, C, I3); return; }
     b -= n3;
@@ -1014,7 +1017,7 @@ inline void launch1d(void (*k)(A...), int64_t items, int block, hipStream_t s, A
 void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int n)
 {
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
-    const int wgs = n * (S / 8 + S / 16 + S / 32 + S / 64);
+    const int wgs = n * (PyrGeo<0>::TILES + PyrGeo<1>::TILES + PyrGeo<2>::TILES + PyrGeo<3>::TILES);
     hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3]);
     PolyPtrs P;
     int grid = ((n * (S / kPolyRows) + 7) >> 3) << 3;      // the 320-px scale: kPolyRows rows per workgroup
