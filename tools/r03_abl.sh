@@ -8,7 +8,7 @@ for flags in "" "-DAVD_FBF_NOGATHER" "-DAVD_FBF_NOGATHER -DAVD_FBF_NOINLOAD" "-D
   python - <<PY
 import json
 d=json.load(open('gpurun_out/r03_abl.json'))
-print('flags [$flags]', 'ms/step', d['ms_per_step'], 'level0 x3', d['stages_ms']['fused_level0'], 'farneback', d['stages_ms']['farneback_and_flow_stats'])
+print('flags [$flags]', 'ms/step', d['ms_per_step'], 'level0 x3', d['stages_ms']['level0_all_iterations'], 'farneback', d['stages_ms']['farneback_and_flow_stats'])
 PY
   cd $GRAFT_REPO_ROOT/ai-video-detector_amd/csrc
 done
