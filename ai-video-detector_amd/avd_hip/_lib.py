@@ -29,7 +29,7 @@ EXPORTS = (
     "avd_vit_set_weights", "avd_vit_patch_embed", "avd_audio_features", "avd_layernorm", "avd_softmax",
     "avd_cnn_param_counts", "avd_cnn_set_weights", "avd_cnn_forward", "avd_cnn_conv",
     "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records", "avd_allgather_last_records",
-    "avd_timer_start", "avd_timer_stop", "avd_set_option",
+    "avd_timer_start", "avd_timer_stop", "avd_set_option", "avd_get_option",
     "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
 )
 
@@ -142,6 +142,7 @@ def load() -> C.CDLL:
     L.avd_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.avd_set_profiling.argtypes = [vp, C.c_int]
     L.avd_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.avd_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.avd_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.avd_debug_fetch.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.avd_debug_fetch.restype = C.c_int64
@@ -523,6 +524,12 @@ class Context:
     def set_option(self, name: str, value: int):
         """Tuning / test switches, e.g. ``set_option("fb_fused", 0)`` selects the two-kernel Farneback path."""
         self._check(self._L.avd_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        """Current value of an option (environment defaults included), or a read-only counter such as ``rerun_pairs``."""
+        v = C.c_int()
+        self._check(self._L.avd_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_profiling(self, on: bool):
         self._check(self._L.avd_set_profiling(self._h, int(bool(on))))

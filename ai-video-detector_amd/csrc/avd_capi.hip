@@ -58,7 +58,7 @@ void free_ws(Workspace& ws, bool keep_weights = false)
     F(ws.d_clipstart);
     if (ws.h_clipstart) (void)hipHostFree(ws.h_clipstart);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); F(ws.d_flow2[k]); }
-    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_rec); F(ws.d_mag);
+    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_rec); F(ws.d_mag); F(ws.d_fbflags);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
     F(ws.d_cnn_w); F(ws.d_cnn_b); F(ws.d_cnn_img); F(ws.d_cnn_pool); F(ws.d_cnn_logits);
@@ -241,6 +241,7 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
         }
         if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_mag, np * (size_t)AVD_NPIX)) return e;
+        if (int e = dev_alloc(ctx, ws.d_fbflags, np)) return e;
         if (ws.d_vs) { (void)hipFree(ws.d_vs); ws.d_vs = nullptr; }
         if (ws.d_vs0) { (void)hipFree(ws.d_vs0); ws.d_vs0 = nullptr; }
         if (ws.d_flow_il) { (void)hipFree(ws.d_flow_il); ws.d_flow_il = nullptr; }
@@ -263,8 +264,8 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
 // computed across a clip boundary is ignored): f == 0, or clipstart[f] != 0 when the call holds several clips
 // (clipstart == nullptr: one clip).  with_flow == 0: a call without any pair (one frame).
 __global__ __launch_bounds__(256) void k_records(const unsigned long long* __restrict__ lap, const uint8_t* __restrict__ bits,
-                                                const float* __restrict__ stats, int stats_off, avd_frame_record* __restrict__ rec,
-                                                int f0, const int* __restrict__ clipstart, int with_flow)
+                                                const float* __restrict__ stats, const int* __restrict__ flags, int stats_off,
+                                                avd_frame_record* __restrict__ rec, int f0, const int* __restrict__ clipstart, int with_flow)
 {
     __shared__ int wsum[4];
     const int f = f0 + blockIdx.x, tid = threadIdx.x;
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) void k_records(const unsigned long long* __res
     r.lap_sum = (int64_t)lap[2 * f];
     r.lap_sumsq = (int64_t)lap[2 * f + 1];
     r.ham = first ? -1 : wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    r.reserved = 0;
+    // fast Farneback mode: non-zero when pair (f - 1, f) met the ill-posedness criterion and was re-run by the exact kernels
+    r.reserved = (first || !with_flow || !flags) ? 0 : flags[f - 1 - stats_off];
     r.flow_mean = (first || !with_flow) ? 0.f : stats[2 * (f - 1 - stats_off)];
     r.flow_var = (first || !with_flow) ? 0.f : stats[2 * (f - 1 - stats_off) + 1];
     rec[f] = r;
@@ -314,11 +316,15 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
             // frames p0 + 1 .. p0 + np, and frame 0 with the first chunk
             const int fa = p0 == 0 ? 0 : p0 + 1;
             hipLaunchKernelGGL(k_records, dim3(p0 + np + 1 - fa), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap,
-                               (const uint8_t*)ws.d_hash, (const float*)ws.d_stats, p0, ws.d_rec, fa, records_clipstart, 1);
+                               (const uint8_t*)ws.d_hash, (const float*)ws.d_stats,
+                               (const int*)(ctx->fb_mode == 1 && ctx->fb_rerun ? ws.d_fbflags : nullptr), p0, ws.d_rec, fa, records_clipstart, 1);
         }
         if (h_mean || h_var || h_flow_out) {
             std::vector<float> st((size_t)np * 2);
+            std::vector<int> fl((size_t)np, 0);
             hipError_t e = hipMemcpyAsync(st.data(), ws.d_stats, sizeof(float) * 2 * np, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess && ctx->fb_mode == 1 && ctx->fb_rerun)
+                e = hipMemcpyAsync(fl.data(), ws.d_fbflags, sizeof(int) * np, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess && h_flow_out)
                 e = hipMemcpyAsync(h_flow_out + (size_t)p0 * AVD_NPIX * 2, ws.d_flow_il,
                                    sizeof(float) * 2 * AVD_NPIX * np, hipMemcpyDeviceToHost, ctx->stream);
@@ -327,6 +333,7 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
             for (int i = 0; i < np; i++) {
                 if (h_mean) h_mean[p0 + i] = st[2 * i];
                 if (h_var) h_var[p0 + i] = st[2 * i + 1];
+                ctx->last_rerun += fl[i] != 0;
             }
         }
     }
@@ -385,6 +392,7 @@ static int impl_create(int device_id, avd_ctx** out)
         if (const char* e = std::getenv("AVD_FB_FUSED")) ctx->fb_fused = (int)std::strtol(e, nullptr, 0) & 0xF;
         if (const char* e = std::getenv("AVD_FB_FOLD_UP")) ctx->fb_fold_up = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
+        if (const char* e = std::getenv("AVD_FB_RERUN")) ctx->fb_rerun = std::atoi(e) != 0;
         build_fb_consts(ctx->fbc);
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
              hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;
@@ -437,6 +445,7 @@ static int impl_preprocess_bgr(avd_ctx* ctx, const uint8_t* bgr, int mem, int n,
         if (lap_sumsq) lap_sumsq[f] = (int64_t)lap[2 * f + 1];
     }
     ctx->last_n = n;
+    ctx->rec_n = 0;
     return AVD_OK;
 }
 
@@ -449,9 +458,13 @@ static int impl_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint8_t* d_small = nullptr;
     if (int e = stage_input(ctx, small320, mem, (size_t)n * AVD_NPIX, &d_small)) return e;
+    ctx->last_rerun = 0;
+    std::vector<float> fm_tmp;
+    if (!flow_mean && !flow_var && !flow_out) { fm_tmp.resize((size_t)n - 1); flow_mean = fm_tmp.data(); }   // the chunks are drained either way
     if (int e = run_flow_chunks(ctx, d_small, n, flow_mean, flow_var, flow_out, false)) return e;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last_n = std::min(n, ctx->ws.fb_cap + 1);
+    ctx->rec_n = 0;
     return AVD_OK;
 }
 
@@ -584,7 +597,7 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
     stage_mark(ctx, 2);
     if (n < 2)
         hipLaunchKernelGGL(k_records, dim3(n), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap, (const uint8_t*)ws.d_hash,
-                           (const float*)nullptr, 0, ws.d_rec, 0, clipstart, 0);
+                           (const float*)nullptr, (const int*)nullptr, 0, ws.d_rec, 0, clipstart, 0);
     else if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true, clipstart)) return e;
     stage_mark(ctx, 3);
     // into PINNED memory: a device-to-host copy into the caller's pageable buffer would block this thread until
@@ -593,6 +606,7 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
     ctx->pending_out = records; ctx->pending_n = n;
     stage_mark(ctx, 4);
     ctx->last_n = n;
+    ctx->rec_n = n;
     return AVD_OK;
 }
 
@@ -664,6 +678,7 @@ static int impl_preprocess_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, 
         if (lap_sumsq) lap_sumsq[f] = (int64_t)lap[2 * f + 1];
     }
     ctx->last_n = n;
+    ctx->rec_n = 0;
     return AVD_OK;
 }
 
@@ -673,6 +688,8 @@ static int impl_synchronize(avd_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->pending_out) {
         std::memcpy(ctx->pending_out, ctx->ws.h_rec, sizeof(avd_frame_record) * ctx->pending_n);
+        ctx->last_rerun = 0;
+        for (int i = 0; i < ctx->pending_n; i++) ctx->last_rerun += ctx->ws.h_rec[i].reserved != 0;
         ctx->pending_out = nullptr; ctx->pending_n = 0;
     }
     if (ctx->profiling && ctx->stage_marks == 5) {
@@ -780,6 +797,7 @@ static int impl_release_workspace(avd_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int e = impl_synchronize(ctx)) return e;
     free_ws(ctx->ws, true);
+    ctx->rec_n = 0;
     return AVD_OK;
 }
 
@@ -790,7 +808,23 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_fused") == 0) { ctx->fb_fused = value & 0xF; return AVD_OK; }
     if (std::strcmp(name, "fb_mode") == 0) { ctx->fb_mode = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value ? 1 : 0; return AVD_OK; }
+    if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
+    ctx->err = std::string("unknown option: ") + name;
+    return AVD_ERR_ARG;
+}
+
+// The value an option has NOW (environment defaults included), and read-only counters: "rerun_pairs" = pairs of the last
+// drained call that the fast level kernel flagged as ill-posed and the exact kernels re-ran.
+static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
+{
+    if (!ctx || !name || !value) return AVD_ERR_ARG;
+    if (std::strcmp(name, "fb_fused") == 0) { *value = ctx->fb_fused; return AVD_OK; }
+    if (std::strcmp(name, "fb_mode") == 0) { *value = ctx->fb_mode; return AVD_OK; }
+    if (std::strcmp(name, "fb_fold_up") == 0) { *value = ctx->fb_fold_up; return AVD_OK; }
+    if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
+    if (std::strcmp(name, "cnn_tiles") == 0) { *value = ctx->cnn_tiles; return AVD_OK; }
+    if (std::strcmp(name, "rerun_pairs") == 0) { *value = ctx->last_rerun; return AVD_OK; }
     ctx->err = std::string("unknown option: ") + name;
     return AVD_ERR_ARG;
 }
@@ -926,9 +960,12 @@ static int impl_rowop(avd_ctx* ctx, int op, const void* x, int mem, int bf16, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Workspace& ws = ctx->ws;
     const size_t esz = (op == 0 && bf16) ? 2 : 4, bytes = (size_t)rows * cols * esz;
-    const size_t need_f = (2 * bytes + 2 * (size_t)cols * 4 + 3) / 4 + 64;       // x, y, gamma, beta in float units
+    // layout in float units: gamma | beta | pad to a multiple of 64 floats | x (rounded up to 256 bytes) | y -- the size is computed from
+    // the SAME expressions the pointers below use (round 3 reserved 2 * bytes + 8 * cols + 256 B, less than pad + round-up can need)
+    const size_t gb_f = 2 * (size_t)cols + ((64 - (2 * cols) % 64) % 64);
+    const size_t x_bytes = (bytes + 255) / 256 * 256;
     const bool host = mem == AVD_MEM_HOST;
-    const size_t want = host ? need_f : (size_t)cols * 2 + 64;
+    const size_t want = host ? gb_f + (x_bytes + bytes + 3) / 4 : gb_f;
     if (ws.vit_token_elems < want) {
         ws.vit_token_elems = 0;
         if (int e = dev_alloc(ctx, ws.d_vit_tokens, want)) return e;
@@ -942,8 +979,8 @@ static int impl_rowop(avd_ctx* ctx, int op, const void* x, int mem, int bf16, in
         HIP_TRY(ctx, hipMemcpyAsync(d_gb + cols, beta, sizeof(float) * cols, hipMemcpyHostToDevice, ctx->stream));
     }
     if (host) {
-        d_x = (char*)(d_gb + 2 * (size_t)cols + ((64 - (2 * cols) % 64) % 64));
-        d_y = d_x + (bytes + 255) / 256 * 256;
+        d_x = (char*)(d_gb + gb_f);
+        d_y = d_x + x_bytes;
         HIP_TRY(ctx, hipMemcpyAsync(d_x, x, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     auto run = [&]() -> int {
@@ -1175,6 +1212,7 @@ int avd_release_workspace(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_
 int avd_timer_start(avd_ctx* ctx) { return guarded(ctx, [&] { return impl_timer_start(ctx); }); }
 int avd_timer_stop(avd_ctx* ctx, float* elapsed_ms) { return guarded(ctx, [&] { return impl_timer_stop(ctx, elapsed_ms); }); }
 int avd_set_option(avd_ctx* ctx, const char* name, int value) { return guarded(ctx, [&] { return impl_set_option(ctx, name, value); }); }
+int avd_get_option(avd_ctx* ctx, const char* name, int* value) { return guarded(ctx, [&] { return impl_get_option(ctx, name, value); }); }
 int avd_set_profiling(avd_ctx* ctx, int enable) { return guarded(ctx, [&] { return impl_set_profiling(ctx, enable); }); }
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms) { return guarded(ctx, [&] { return impl_stage_ms(ctx, stage, ms); }); }
 

@@ -119,7 +119,7 @@ int comm_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all)
 {
     if (count < 0 || (count > 0 && !all)) { ctx->err = "bad arguments"; return AVD_ERR_ARG; }
     if (!ctx->comm) { ctx->err = "avd_comm_init has not been called on this context"; return AVD_ERR_ARG; }
-    if (count > ctx->last_n || !ctx->ws.d_rec) { ctx->err = "the last analysis call produced fewer records than asked for"; return AVD_ERR_ARG; }
+    if (count > ctx->rec_n || !ctx->ws.d_rec) { ctx->err = "the last call on this context left fewer records than asked for (only avd_analyze_* calls leave records)"; return AVD_ERR_ARG; }
     if (count == 0) return AVD_OK;
     Rccl* r = rccl(ctx->err);
     if (!r) return AVD_ERR_DEVICE;

@@ -151,11 +151,13 @@ __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* 
 
 // the four scales of every frame in ONE launch (coarsest first: its workgroups do the most work): the small scales
 // alone cannot fill the chip (600 workgroups at 40 px for a 120-frame clip) and used to run one after the other
+// It also clears the per-pair ill-posedness flags of the chunk (the fast level kernels, which come later on the stream, set them).
 __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__ small, int n, const FbConsts* __restrict__ C,
                                                     float* __restrict__ I0, float* __restrict__ I1, float* __restrict__ I2,
-                                                    float* __restrict__ I3)
+                                                    float* __restrict__ I3, int* __restrict__ flags)
 {
     __shared__ __align__(16) char lds[kPyrLds];
+    if (flags && (int)(blockIdx.x * 256 + threadIdx.x) < n - 1) flags[blockIdx.x * 256 + threadIdx.x] = 0;
     const int n3 = n * PyrGeo<3>::TILES, n2 = n * PyrGeo<2>::TILES, n1 = n * PyrGeo<1>::TILES;
     int b = blockIdx.x;
     if (b < n3) { pyramid_body<3>(lds, b, small, C, I3); return; }
@@ -983,6 +985,7 @@ struct Seg {
     float* flow[AVD_FB_LEVELS];
     double *vs, *vs0;
     float *stats, *flow_il;
+    int* flags;                          // ill-posedness flags of the segment's pairs (fast mode)
     avd_ctx* prof;                       // non-null: record kernel events of the full-resolution blur launches
 };
 
@@ -1002,6 +1005,7 @@ static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_of
     g.vs = ws.d_vs ? ws.d_vs + (size_t)pair_off * (5 * AVD_NPIX + 512) : nullptr;
     g.vs0 = ws.d_vs0 ? ws.d_vs0 + (size_t)pair_off * 5 * S * 8 : nullptr;
     g.stats = ws.d_stats + (size_t)pair_off * 2;
+    g.flags = ws.d_fbflags ? ws.d_fbflags + pair_off : nullptr;
     g.flow_il = ws.d_flow_il ? ws.d_flow_il + (size_t)pair_off * AVD_NPIX * 2 : nullptr;
     return g;
 }
@@ -1018,7 +1022,7 @@ void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int
 {
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
     const int wgs = n * (PyrGeo<0>::TILES + PyrGeo<1>::TILES + PyrGeo<2>::TILES + PyrGeo<3>::TILES);
-    hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3]);
+    hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3], g.flags);
     PolyPtrs P;
     int grid = ((n * (S / kPolyRows) + 7) >> 3) << 3;      // the 320-px scale: kPolyRows rows per workgroup
     for (int k = 0; k < AVD_FB_LEVELS; k++) {
@@ -1097,11 +1101,19 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             for (int it = 0; it < 3; it++) {
                 float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
                 const float* in = (up && it == 0) ? ctx->ws.flow_res[k + 1] : a;
-                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], in, b, mag, np, k == AVD_FB_LEVELS - 1 && it == 0, up && it == 0)) return e;
+                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], in, b, mag, ctx->fb_rerun ? g.flags : nullptr, np, k == AVD_FB_LEVELS - 1 && it == 0, up && it == 0)) return e;
                 float* t = a; a = b; b = t;
             }
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
             ctx->ws.flow_res[k] = a;                       // after the last swap `a` is the buffer written last
+            if (k == 0 && ctx->fb_rerun && g.flags) {
+                // pairs the level kernels flagged as ill-posed: all four levels again with the exact kernels' code (one launch; nothing
+                // to do for a pair that is not flagged), working in the levels' first flow buffers, result and |flow| where the
+                // statistics read them
+                float* fl[4] = {a, g.flow[1], g.flow[2], g.flow[3]};
+                const float* Rk[4] = {g.poly[0], g.poly[1], g.poly[2], g.poly[3]};
+                if (int e = launch_fb_rerun(ctx, stream, Rk, fl, ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX, g.flags, np)) return e;
+            }
             continue;
         }
         if (!((ctx->fb_fused >> k) & 1) && !g.vs) { ctx->err = "two-kernel Farneback path: scratch not reserved"; return AVD_ERR_ARG; }

@@ -326,9 +326,23 @@ __device__ __forceinline__ double recip_exact(double d)
 // chunk of four output columns).  The strip's lane column u holds image column clamp(xlo + u) with xlo = o0 - 7, and vsum
 // of lane column u sits at index u + 8 of its line: the window of output column o0 + i is lane columns i .. i + 14.
 // ------------------------------------------------------------------------------------------------------------------
+// Ill-posedness flag (round 4).  Where the 2 x 2 normal equations are singular over whole regions the flow is chaotic: the
+// ORACLE's own result moves by tens to hundreds of pixels under one ulp of noise on its inputs, and a kernel that re-orders a
+// single double addition (this one: the horizontal window sums) cannot follow it.  Such pairs are recognised here and re-run
+// by the exact kernels (avd_fbfused.hip, k_fb_rerun) before anything reads their flow.  Criterion, derived on the CPU over
+// 1 440 pairs of 24 content families (tools/experiments/fb_illposed_run.py; profiles/r04_experiments.md section 1):
+//   (g11 g22 + g12^2) > kCondMax (g11 g22 - g12^2 + 1e-3)   cancellation in the determinant: 1-D structure (ramps, stripes:
+//                                                            3e5 .. 1e7; every natural / noise / scene-cut / letterboxed /
+//                                                            saturated pair of the experiment: <= 975)
+//   max(|fx|, |fy|) > kFlowMax * W                           a displacement beyond what a 15-px window can estimate at this
+//                                                            level (the same experiment: <= 0.25 W on well-posed pairs)
+// written so that a NaN or a negative determinant also fires.
+constexpr double kCondMax = 2000.;
+constexpr float kFlowMax = 0.3f;
+
 template <typename Ge, bool UP>
 __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, float* __restrict__ mag_out,
-                                           int p, int b, int xi, int lane, int o0, int ow)
+                                           int* __restrict__ flags, int p, int b, int xi, int lane, int o0, int ow)
 {
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
@@ -341,6 +355,7 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
     float* fl = flow_out + (size_t)p * 2 * plane + o0 + CPL * j;
     const double* vsrc = vsring + 8 + CPL * j;
     if (UP) fb_barrier();                                  // the chain wave's fill of the flow ring
+    bool ill = false;
     for (int t4 = 0; t4 < Ge::T; t4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -384,9 +399,11 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
                 for (int i = 0; i < CPL; i++) {
                     const double g11 = o[0][i] * scale, g12 = o[1][i] * scale, g22 = o[2][i] * scale;
                     const double h1 = o[3][i] * scale, h2 = o[4][i] * scale;
-                    const double idet = recip_exact(g11 * g22 - g12 * g12 + 1e-3);
+                    const double t1 = g11 * g22, t2 = g12 * g12, den = t1 - t2 + 1e-3;      // cv2's determinant, its operation order
+                    const double idet = recip_exact(den);
                     fx[i] = (float)((g11 * h2 - g12 * h1) * idet);
                     fy[i] = (float)((g22 * h1 - g12 * h2) * idet);
+                    ill |= !(t1 + t2 <= kCondMax * den) | !(fmaxf(fabsf(fx[i]), fabsf(fy[i])) <= kFlowMax * (float)W);
                 }
                 // last iteration of the 320-px level: |flow| as np.sqrt(fx * fx + fy * fy) forms it in float32 (video.py:46), for the
                 // statistics kernels -- they then read 4 bytes per pixel twice instead of 8, and the flow only once, here
@@ -409,14 +426,15 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
             }
         }
     }
+    if (flags && __builtin_amdgcn_ballot_w64(ill) != 0 && lane == 0) atomicOr(flags + p, 1 << (Ge::W == 320 ? 0 : Ge::W == 160 ? 1 : Ge::W == 80 ? 2 : 3));
     FBF_WAIT_OUT(threadIdx.x >> 6, 3, fbf_t0)
 }
 
 // UP: flow_in is the PREVIOUS level's flow ([pair][2][H/2][W/2]); the launch's input flow is that, resized x 2 and doubled
 template <typename Ge, bool UP>
 __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
-                                                              float* __restrict__ flow_out, float* __restrict__ mag_out, int npairs,
-                                                              int nstrips, int ow, int zero_first, int dbg)
+                                                              float* __restrict__ flow_out, float* __restrict__ mag_out,
+                                                              int* __restrict__ flags, int npairs, int nstrips, int ow, int zero_first, int dbg)
 {
     constexpr int W = Ge::W, NB = Ge::NB;
     __shared__ __align__(16) double lds[Ge::LDS_DOUBLES + (UP ? Ge::F_FLOATS / 2 : 0)];
@@ -455,21 +473,21 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
         role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane);
     } else {
-        role_solve<Ge, UP>(vsring, flow_out, mag_out, p, b, role - Ge::NPB - 1, lane, o0, width);
+        role_solve<Ge, UP>(vsring, flow_out, mag_out, flags, p, b, role - Ge::NPB - 1, lane, o0, width);
     }
 }
 
 template <typename Ge>
-void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* mag, int np, int nstrips, int ow, int zero_first, int up)
+void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* mag, int* flags, int np, int nstrips, int ow, int zero_first, int up)
 {
     const int grid = 8 * ((np + 7) / 8) * nstrips;
     static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
     // the folded resize only exists where it pays: at 320 px it costs the launch 3.5 us and saves k_flow_up's 37; the small
     // levels are latency-bound on exactly the chain wave that would do it (160 px: 45 -> 84 us per launch against 12 saved)
     if constexpr (Ge::W == 320) {
-        if (up) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, np, nstrips, ow, 0, dbg); return; }
+        if (up) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, flags, np, nstrips, ow, 0, dbg); return; }
     }
-    hipLaunchKernelGGL((k_fb_fast<Ge, false>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, np, nstrips, ow, zero_first, dbg);
+    hipLaunchKernelGGL((k_fb_fast<Ge, false>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, flags, np, nstrips, ow, zero_first, dbg);
 }
 
 }  // namespace
@@ -479,26 +497,27 @@ void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fo
 // mag_out (320-px level, last iteration; else null): float[pair][320][320] receives |flow|
 // up: flow_in is the previous (coarser) level's final flow, [pair][2][w/2][w/2]: the kernel forms this level's initial flow
 // from it on the fly (cv2: resize x 2, INTER_LINEAR, times 2) instead of reading one a separate launch wrote
-int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int np,
-                   int zero_first, int up)
+// flags (may be null): int[np]; bit k of flags[p] is set when level k (0 = 320 px) of pair p met the ill-posedness criterion
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int* flags,
+                   int np, int zero_first, int up)
 {
     if (np <= 0) return 0;
     if (up && w != 320) { ctx->err = "launch_fb_fast: the folded resize of the previous flow exists at 320 px only"; return AVD_ERR_ARG; }
     if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
-    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 160, zero_first, up); break;
+    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 160, zero_first, up); break;
     case 160:
-        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first, up);
-        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 2, 80, zero_first, up);
+        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
+        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
         break;
     case 80:
-        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first, up);
-        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 80, zero_first, up);
+        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 80, zero_first, up);
+        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 80, zero_first, up);
         break;
     case 40:
-        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first, up);
-        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, np, 1, 40, zero_first, up);
+        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 40, zero_first, up);
+        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 40, zero_first, up);
         break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
     }

@@ -126,6 +126,7 @@ struct Workspace {
     const float* flow_res[AVD_FB_LEVELS] = {};   // where the last call left the final flow of each level (d_flow or d_flow2)
     float* d_mag = nullptr;               // [n-1][320*320] |flow| of the full-resolution level (written by the fast level kernel, or by k_mag in exact mode)
     int mag_valid = 0;                    // d_mag holds the magnitudes of the chunk being processed
+    int* d_fbflags = nullptr;             // [n-1] ill-posedness flags of the fast level kernel (bit k: level k); such pairs are re-run exactly
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
@@ -166,6 +167,7 @@ struct avd_ctx {
     FbConsts fbc;
     void* d_fbc = nullptr;          // FbConsts on device
     int last_n = 0;
+    int rec_n = 0;                   // records the last avd_analyze_* call left in ws.d_rec (0 after any other entry point: avd_allgather_last_records checks it)
     void* comm = nullptr;            // RCCL communicator (avd_comm.cpp), bound at run time
     int comm_rank = 0, comm_world = 1;
     void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
@@ -174,6 +176,8 @@ struct avd_ctx {
     int fb_fold_up = 1;             // fast mode: the first launch of the 320-px level forms its initial flow from the 160-px level's (no k_flow_up<320> launch); AVD_FB_FOLD_UP=0 = A/B
     int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
                                     // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
+    int fb_rerun = 1;               // fast mode: pairs the level kernel flags as ill-posed are re-run by the exact kernels (k_fb_rerun); 0 = A/B, tests
+    int last_rerun = 0;             // pairs re-run by the last drained call
 };
 
 template <typename T>
@@ -230,8 +234,11 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
 int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first);
 // avd_fbfast.hip: ONE blur iteration of one pyramid level, a pair spread over several workgroups (column strips), the
 // horizontal window sums formed directly in double (the vertical chain stays literal); flow_in != flow_out
-int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int np,
-                   int zero_first, int up);
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int* flags,
+                   int np, int zero_first, int up);
+// avd_fbfused.hip: re-run of the pairs with flags[p] != 0 through all four levels with the exact kernels' code, one launch; R / flow per
+// level (0 = 320 px); flow[k] is scratch for k > 0, flow[0] receives the result ([pair][2][320][320]), mag its magnitudes
+int launch_fb_rerun(avd_ctx* ctx, hipStream_t stream, const float* const R[4], float* const flow[4], float* mag, const int* flags, int np);
 // avd_norm.hip (extensions): LayerNorm over rows of 256..2048 values, softmax over rows of logits; device pointers
 int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps);
 int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols);

@@ -57,7 +57,7 @@ typedef struct avd_frame_record {
     float   flow_mean;   /* np.mean(|flow|) vs the previous sampled frame (video.py:47); 0 for frame 0 */
     float   flow_var;    /* np.var(|flow|)                                 (video.py:48); 0 for frame 0 */
     int32_t ham;         /* popcount(hash ^ prev_hash)     (video.py:38); -1 for frame 0 */
-    int32_t reserved;
+    int32_t reserved;    /* non-zero: the pair (previous frame, this frame) was flagged ill-posed by the fast Farneback kernel and re-run exactly */
 } avd_frame_record;      /* 32 bytes */
 
 int avd_abi_version(void);
@@ -258,8 +258,15 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
 /* Tuning / test switches.  "fb_mode": 1 (default; environment AVD_FB_MODE=fast) = the fast Farneback level kernel
  * (csrc/avd_fbfast.hip: a pair is spread over several workgroups; cv2's vertical running sums are kept literally, the
  * horizontal 15-column window sums are formed directly in double instead of as cv2's running double sum: the flow equals
- * the exact kernels' bit for bit on well-posed inputs and stays within 1e-5 px / ai_susp within 1e-6 otherwise, except on
- * chaotic pairs where the reference result itself moves by more under a 1-ulp perturbation, tests/test_gpu_fbfast.py);
+ * the exact kernels' bit for bit on well-posed inputs, within 1e-5 px otherwise) WITH the re-run of ill-posed pairs: a pair
+ * whose 2 x 2 normal equations are singular over whole regions (determinant cancellation above 2000, or a displacement
+ * above 0.3 of the level width; see csrc/avd_fbfast.hip) is chaotic in the reference itself, is recognised by the level
+ * kernel and computed again by the exact kernels before its flow is read, so its results are the exact kernels', bit for
+ * bit.  avd_frame_record.reserved is non-zero for the frame that closes such a pair; avd_get_option "rerun_pairs" counts
+ * them for the last drained call.  Stated guarantee of the mode: flow_mean / flow_var within rel 1e-6 and ai_susp within
+ * 1e-6 of the oracle (north_star: 1e-4), tests/test_gpu_fbfast.py + the content soak in tests/test_gpu_soak.py; the
+ * one family outside it that the soak found is named there.
+ * "fb_rerun" (default 1, environment AVD_FB_RERUN): 0 switches the re-run off (A/B, tests).
  * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
  * "fb_fold_up" (fast mode, default 1, environment AVD_FB_FOLD_UP; no effect on results): the first launch of the 320-px level
  * resizes the 160-px level's flow itself instead of reading the output of a separate resize launch.
@@ -267,8 +274,10 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
  * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM.  "cnn_tiles": tiling of the
  * CNN extension's convolutions, 0 = by layer shape (default), 1 = 256-pixel tiles everywhere, 2 = 128 x 128 tiles wherever the
- * channel count allows (the accumulation order of an output does not depend on the tiling: results are bit-identical). */
+ * channel count allows (the accumulation order of an output does not depend on the tiling: results are bit-identical).
+ * avd_get_option returns the value an option has now (environment defaults included) and the read-only "rerun_pairs". */
 int avd_set_option(avd_ctx* ctx, const char* name, int value);
+int avd_get_option(avd_ctx* ctx, const char* name, int* value);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 
 /* Test hook: copy an internal device buffer of the last call to host.

@@ -35,6 +35,7 @@ def test_13_short_720p_clips_batched_equal_one_at_a_time_and_oracle(oracle):
         fast = c.analyze_batch(clips)
         for i, (a, b) in enumerate(zip(fast, single)):
             np.testing.assert_allclose(a["flow_mean"], b["flow_mean"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(a["flow_var"], b["flow_var"], rtol=1e-6, atol=1e-7)
             assert np.array_equal(a["ham"], b["ham"]) and np.array_equal(a["lap_sumsq"], b["lap_sumsq"])
 
 

@@ -1,20 +1,22 @@
-"""The two Farneback level kernels against the oracle (reference site: cv2.calcOpticalFlowFarneback at
+"""The Farneback level kernels against the oracle (reference site: cv2.calcOpticalFlowFarneback at
 app/analyzers/video.py:45).
 
   fb_mode = 1 "fast"  (default, csrc/avd_fbfast.hip): cv2's vertical running sums literally, the horizontal 15-column
-                      window sums formed directly in double instead of as cv2's running double sum.  Tolerance stated
-                      here: dense flow max |delta| <= 1e-5 px, flow_mean / flow_var relative 1e-6, ai_susp |delta| <= 1e-6
-                      (north_star allows 1e-4).  In practice the flow is bit-identical on every well-posed input (the tests
-                      print how many values differ: 0, or a few hundred at 1e-13 px).
+                      window sums formed directly in double instead of as cv2's running double sum -- and every pair the
+                      kernel flags as ILL-POSED re-run by the exact kernels (k_fb_rerun) before its flow is read.
+                      Guarantee asserted here, with NO exception for any pair: flagged pairs bit-identical to the oracle
+                      (they ARE the exact kernels' result); the others dense flow max |delta| <= 1e-5 px (in practice 0
+                      differing values), flow_mean / flow_var relative 1e-6; ai_susp |delta| <= 1e-6 (north_star: 1e-4);
+                      summary and the fused result of the hard-set clip equal to the oracle chain's.
+  fb_rerun = 0        the fast kernels alone (A/B): on the ill-posed pairs of the hard set they differ from the oracle by
+                      far more than any tolerance -- the negative control that shows the re-run is what closes the gap.
   fb_mode = 0 "exact" (csrc/avd_fbfused.hip and the two-kernel path): bit-identical, asserted with array_equal.
 
 ILL-POSED pairs.  Three pairs of the hard set (a saturated step edge against an unrelated ramp, a ramp against itself
 rolled by 25 px) make the 2 x 2 normal equations singular over whole regions: the oracle's own flow there is hundreds of
-pixels on a 320-px image and moves by tens to hundreds of pixels when ONE ulp of noise is put on its pyramid or on its
-up-sampled flow (oracle model switches AVDO_MODEL_JITTER_*, oracle/avd_oracle.h).  No implementation that re-orders a
-single double addition can follow a chaotic result; only the exact kernels do (and are asserted to).  For those pairs the
-fast kernel is held to the oracle's OWN sensitivity: |fast - oracle| <= 2 x |oracle(+-1 ulp) - oracle|, measured per pair,
-and ai_susp, the quantity the reference derives from the flow (video.py:54-56), still to 1e-6.
+pixels on a 320-px image and moves by tens to hundreds of pixels when ONE ulp of noise is put on its pyramid.  The level
+kernel recognises them (determinant cancellation > 2000 or a displacement > 0.3 of the level width; criterion derived in
+tools/experiments/fb_illposed_run.py) and the exact kernels compute them again.
 """
 import numpy as np
 import pytest
@@ -30,12 +32,15 @@ SUSP_TOL = 1e-6
 @pytest.fixture(scope="module")
 def ctxs():
     import avd_hip
-    fast, exact = avd_hip.Context(0), avd_hip.Context(0)
+    fast, exact, fastonly = avd_hip.Context(0), avd_hip.Context(0), avd_hip.Context(0)
     fast.set_option("fb_mode", 1)
+    fast.set_option("fb_rerun", 1)
     exact.set_option("fb_mode", 0)
-    yield {"fast": fast, "exact": exact}
-    fast.close()
-    exact.close()
+    fastonly.set_option("fb_mode", 1)
+    fastonly.set_option("fb_rerun", 0)
+    yield {"fast": fast, "exact": exact, "fastonly": fastonly}
+    for c in (fast, exact, fastonly):
+        c.close()
 
 
 def _smalls(oracle, clip):
@@ -60,20 +65,7 @@ def _hard_frames():
                      stripes[0], stripes[1], box[0], box[1]])
 
 
-def _oracle_sensitivity(oracle, a, b, ref):
-    """max |oracle with +-1 ulp on every pyramid pixel / on every up-sampled flow value - oracle| for one pair."""
-    lib = oracle.lib()
-    worst = 0.0
-    try:
-        for model in (2, 4):                   # AVDO_MODEL_JITTER_PYRAMID, AVDO_MODEL_JITTER_FLOW
-            lib.avdo_set_model(model)
-            worst = max(worst, float(np.abs(oracle.farneback(a, b) - ref).max()))
-    finally:
-        lib.avdo_set_model(0)
-    return worst
-
-
-def _check_pairs(ctxs, oracle, frames, tag, ill_posed_ok=False):
+def _check_pairs(ctxs, oracle, frames, tag, expect_rerun=None):
     want = [oracle.farneback(frames[p], frames[p + 1]) for p in range(len(frames) - 1)]
     stats = [oracle.flow_stats(f) for f in want]
     # exact kernels: bit-identical
@@ -81,48 +73,82 @@ def _check_pairs(ctxs, oracle, frames, tag, ill_posed_ok=False):
     for p, o in enumerate(want):
         assert np.array_equal(flow[p], o), (tag, "exact", p, int(np.count_nonzero(flow[p] != o)))
         assert fm[p] == stats[p][0] and fv[p] == stats[p][1], (tag, "exact", p)
-    # fast kernel: within the stated tolerance
+    # default mode (fast kernels + re-run of flagged pairs): the stated tolerance on EVERY pair, no carve-out
     fm, fv, flow = ctxs["fast"].farneback_pairs(frames, want_flow=True)
+    rerun = ctxs["fast"].get_option("rerun_pairs")
     ndiff, worst = 0, 0.0
     for p, o in enumerate(want):
         d = np.abs(flow[p].astype(np.float64) - o.astype(np.float64))
         ndiff += int(np.count_nonzero(flow[p] != o))
-        if d.max() > FLOW_TOL and ill_posed_ok:
-            sens = _oracle_sensitivity(oracle, frames[p], frames[p + 1], o)
-            print(f"[fbfast] {tag} pair {p}: ill-posed, oracle flow up to {np.abs(o).max():.0f} px moves by {sens:.3g} px under "
-                  f"+-1 ulp; fast differs by {d.max():.3g} px")
-            assert sens > 100 * FLOW_TOL and d.max() <= 2 * sens, (tag, "fast", p, float(d.max()), sens)
-            continue
         worst = max(worst, float(d.max()))
         assert d.max() <= FLOW_TOL, (tag, "fast", p, float(d.max()))
         assert fm[p] == pytest.approx(stats[p][0], rel=1e-6, abs=1e-7), (tag, p)
         assert fv[p] == pytest.approx(stats[p][1], rel=1e-6, abs=1e-7), (tag, p)
     assert np.isfinite(flow).all()
-    print(f"[fbfast] {tag}: {ndiff} of {flow.size} flow values differ from the oracle, max |delta| = {worst:.3g} px")
+    print(f"[fbfast] {tag}: {ndiff} of {flow.size} flow values differ from the oracle, max |delta| = {worst:.3g} px, {rerun} pairs re-run")
+    if expect_rerun is not None:
+        assert rerun == expect_rerun, (tag, rerun)
     return ndiff, worst
 
 
 def test_flow_on_smooth_clips(ctxs, oracle):
     """The synthetic clips of the parity suite: translation, duplicates, one scene cut (flow up to ~25 px)."""
     clip = synth.make_clip(7, 360, 640, seed=11, dup_every=3)
-    _check_pairs(ctxs, oracle, _smalls(oracle, clip), "smooth 360p")
+    _check_pairs(ctxs, oracle, _smalls(oracle, clip), "smooth 360p", expect_rerun=0)
     clip = synth.make_clip(4, 720, 1280, seed=1, dup_every=0)
-    _check_pairs(ctxs, oracle, _smalls(oracle, clip), "720p with scene cut")
+    _check_pairs(ctxs, oracle, _smalls(oracle, clip), "720p with scene cut", expect_rerun=0)
 
 
 def test_flow_on_hard_inputs(ctxs, oracle):
     """White noise (erratic flow, warps leave the image), constant and saturated step images (every sum is zero or
     cancels), ramps with a 25 px shift, 1-D stripes (aperture problem: the 2 x 2 system is near singular), a flat image
-    with one box."""
+    with one box.  Every pair within the stated tolerance; the ill-posed ones (4, 5, 6: step / ramp / rolled ramp) are
+    flagged and re-run, so they are bit-identical."""
     frames = _hard_frames()
-    _check_pairs(ctxs, oracle, frames, "hard set", ill_posed_ok=True)
-    # what the reference derives from the flow: ai_susp of the hard set run as a "clip" (video.py:54-57)
+    _check_pairs(ctxs, oracle, frames, "hard set")
+    want = [oracle.farneback(frames[p], frames[p + 1]) for p in range(len(frames) - 1)]
+    fm, fv, flow = ctxs["fast"].farneback_pairs(frames, want_flow=True)
+    for p in (4, 5, 6):
+        assert np.array_equal(flow[p], want[p]), p
+    # negative control: without the re-run the fast kernels cannot follow these pairs (this is what the re-run closes)
+    _, _, flow0 = ctxs["fastonly"].farneback_pairs(frames, want_flow=True)
+    assert ctxs["fastonly"].get_option("rerun_pairs") == 0
+    assert max(float(np.abs(flow0[p] - want[p]).max()) for p in (4, 5, 6)) > 100 * FLOW_TOL
+    # what the reference derives from the flow, for the hard set run as a "clip": timeline (video.py:54-57), summary
+    # (video.py:61-71) and the fused result (fusion.py:16-109) -- equal to the oracle chain's
     import avd_hip
+    from app.analyzers import fusion
     clip = np.repeat(frames[..., None], 3, axis=3)
     meta = {"width": 320, "height": 320, "fps": 30.0, "duration": 6.0}
-    want = oracle.analyze_sampled_frames(clip, meta)
-    got = avd_hip.FrameAnalyzer(ctx=ctxs["fast"]).analyze(clip, meta)
-    np.testing.assert_allclose(got["timeline"], want["timeline"], rtol=0, atol=SUSP_TOL)
+    want_v = oracle.analyze_sampled_frames(clip, meta)
+    got_v = avd_hip.FrameAnalyzer(ctx=ctxs["fast"]).analyze(clip, meta)
+    np.testing.assert_allclose(got_v["timeline"], want_v["timeline"], rtol=0, atol=SUSP_TOL)
+    for key, val in want_v["summary"].items():
+        assert got_v["summary"][key] == pytest.approx(val, rel=1e-6, abs=1e-9), key
+    audio = {"scores": {}, "flags_audio": {"error": "FileNotFoundError"}, "timeline": [0.5] * 6}
+    hints = {"bpp": 0.1, "compression": "normal", "dup_avg": 0.0}
+    fw = fusion.fuse(dict(audio, timeline=list(audio["timeline"])), {k: (list(v) if isinstance(v, list) else v) for k, v in want_v.items()}, hints)
+    fg = fusion.fuse(dict(audio, timeline=list(audio["timeline"])), {k: (list(v) if isinstance(v, list) else v) for k, v in got_v.items()}, hints)
+    assert fg["result"] == fw["result"]
+    np.testing.assert_allclose(fg["timeline_binned"], fw["timeline_binned"], rtol=0, atol=SUSP_TOL)
+    assert fg["peaks"] == fw["peaks"]
+
+
+def test_rerun_records_mark_the_pairs(ctxs, oracle):
+    """avd_analyze_frames: the record of the frame that closes a re-run pair carries the level mask in `reserved`, the
+    counter avd_get_option("rerun_pairs") agrees, and a context with the re-run switched off marks nothing."""
+    frames = _hard_frames()
+    clip = np.repeat(frames[..., None], 3, axis=3)
+    rec = ctxs["fast"].analyze_frames(clip)
+    marked = [int(i) for i in np.nonzero(rec["reserved"])[0]]
+    assert set((5, 6, 7)) <= set(marked), marked          # pairs 4, 5, 6 close at frames 5, 6, 7
+    assert ctxs["fast"].get_option("rerun_pairs") == len(marked)
+    rec0 = ctxs["fastonly"].analyze_frames(clip)
+    assert not rec0["reserved"].any() and ctxs["fastonly"].get_option("rerun_pairs") == 0
+    small, _, _, _ = oracle.preprocess_bgr(clip)
+    fm, fv = oracle.farneback_pairs(small)
+    np.testing.assert_allclose(rec["flow_mean"][1:], fm, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rec["flow_var"][1:], fv, rtol=1e-6, atol=1e-7)
 
 
 def test_strip_seams_and_borders(ctxs, oracle):
@@ -130,7 +156,7 @@ def test_strip_seams_and_borders(ctxs, oracle):
     the flow must not show the seam.  White noise makes every column's sums different."""
     frames = synth.random_frames(3, 320, 320, seed=77)[..., 1].copy()
     want = oracle.farneback(frames[0], frames[1])
-    _, _, flow = ctxs["fast"].farneback_pairs(frames[:2], want_flow=True)
+    _, _, flow = ctxs["fastonly"].farneback_pairs(frames[:2], want_flow=True)
     d = np.abs(flow[0] - want)
     for cols in (slice(150, 170), slice(0, 8), slice(312, 320)):
         assert d[:, cols].max() <= FLOW_TOL
@@ -146,6 +172,7 @@ def test_folded_resize_of_the_previous_flow_is_bit_identical(oracle):
             _hard_frames()]
     with avd_hip.Context(0) as c:
         c.set_option("fb_mode", 1)
+        c.set_option("fb_rerun", 0)                        # the fast kernels themselves, on every pair
         for frames in sets:
             c.set_option("fb_fold_up", 0)
             fm0, fv0, flow0 = c.farneback_pairs(frames, want_flow=True)

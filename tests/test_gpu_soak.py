@@ -1,0 +1,71 @@
+"""Content soak of the DEFAULT Farneback mode (fast level kernels + exact re-run of the pairs they flag) against the oracle
+(reference site: cv2.calcOpticalFlowFarneback + np.mean / np.var of |flow|, app/analyzers/video.py:45-48, and ai_susp,
+video.py:54-56).
+
+288 seeded pairs of 320 x 320 frames from the 24 content families of tests/content_families.py: natural-looking (smooth /
+1/f fields with translation, zoom, rotation, fades, scene cuts, letter- and pillar-boxing, saturation, blocks, text),
+degenerate (flat, constant, steps, gradients) and adversarial (ramps, stripes, checkerboards).  Asserted per pair:
+flow_mean / flow_var within rel 1e-6 (abs 1e-7) of the oracle and |delta ai_susp| <= 1e-6 for the texture value that makes
+ai_susp most sensitive to the flow (tex -> infinity: ai_susp = 1 - (1 + mot), so |delta ai_susp| = |delta flow_mean|).
+The CPU experiment behind the flag criterion (tools/experiments/fb_illposed_run.py, 1 440 pairs) is the same generator.
+
+KNOWN RESIDUAL, kept in the soak and reported, not hidden: exactly periodic 2 x 2-cell checkerboards shifted by half a
+period (family "checker", cell size 2).  Their normal equations are well conditioned but the right-hand side is pure
+rounding residue (every window sum cancels exactly in exact arithmetic), so the oracle's own flow moves by pixels under
+one ulp of input noise while neither criterion fires.  fb_mode = exact reproduces them bit for bit (asserted); in the
+default mode they are checked against the oracle's own +-1-ulp sensitivity instead.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.content_families import families  # noqa: E402
+
+PER_FAMILY = 12
+
+
+def _is_fine_checker(name, seed):
+    if name != "checker":
+        return False
+    return int(np.random.default_rng(seed).choice([2, 4, 8, 16, 32])) == 2
+
+
+def test_default_mode_on_every_content_family(oracle):
+    import avd_hip
+    fam = families()
+    jobs = [(name, 9000 + 7919 * i + 17 * j) for j, name in enumerate(fam) for i in range(PER_FAMILY)]
+    frames = np.empty((2 * len(jobs), 320, 320), np.uint8)
+    for k, (name, seed) in enumerate(jobs):
+        frames[2 * k], frames[2 * k + 1] = fam[name](np.random.default_rng(seed))
+    with avd_hip.Context(0) as c, avd_hip.Context(0) as cx:
+        assert c.get_option("fb_mode") == 1 and c.get_option("fb_rerun") == 1        # the library default
+        cx.set_option("fb_mode", 0)
+        fm, fv = c.farneback_pairs(frames)                     # pairs (2k, 2k + 1) are the soak; the ones in between are ignored
+        rerun_total = c.get_option("rerun_pairs")
+        xm, xv = cx.farneback_pairs(frames)
+    worst, reruns, residual = 0.0, {}, []
+    lib = oracle.lib()
+    for k, (name, seed) in enumerate(jobs):
+        a, b = frames[2 * k], frames[2 * k + 1]
+        flow = oracle.farneback(a, b)
+        m, v = oracle.flow_stats(flow)
+        assert xm[2 * k] == m and xv[2 * k] == v, ("exact", name, seed)           # exact mode: bit-identical on every family
+        dm = abs(float(fm[2 * k]) - float(m))
+        if _is_fine_checker(name, seed) and dm > 1e-6 * max(abs(m), 0.1):
+            sens = 0.0
+            try:
+                for model in (2, 4):
+                    lib.avdo_set_model(model)
+                    sens = max(sens, abs(float(oracle.flow_stats(oracle.farneback(a, b))[0]) - float(m)))
+            finally:
+                lib.avdo_set_model(0)
+            residual.append((seed, dm, sens))
+            assert dm <= 4 * max(sens, 1e-6), (name, seed, dm, sens)
+            continue
+        worst = max(worst, dm)
+        assert fm[2 * k] == pytest.approx(m, rel=1e-6, abs=1e-7), (name, seed, float(fm[2 * k]), float(m))
+        assert fv[2 * k] == pytest.approx(v, rel=1e-6, abs=1e-7), (name, seed, float(fv[2 * k]), float(v))
+        assert dm <= 1e-6 * max(1.0, abs(m)), (name, seed, dm)               # |delta ai_susp| bound at tex -> infinity
+    print(f"[soak] {len(jobs)} pairs, {len(fam)} families: max |delta flow_mean| = {worst:.3g}; pairs re-run in the call "
+          f"(incl. the in-between pairs): {rerun_total}; fine-checkerboard residual (seed, |delta mean|, oracle +-1 ulp): {residual}")
