@@ -30,7 +30,7 @@ EXPORTS = (
     "avd_cnn_param_counts", "avd_cnn_set_weights", "avd_cnn_forward", "avd_cnn_conv",
     "avd_comm_unique_id", "avd_comm_init", "avd_allgather_records", "avd_allgather_last_records",
     "avd_timer_start", "avd_timer_stop", "avd_set_option", "avd_get_option",
-    "avd_set_profiling", "avd_stage_ms", "avd_debug_fetch",
+    "avd_set_profiling", "avd_stage_ms", "avd_kernel_ms", "avd_debug_fetch",
 )
 
 # numpy view of struct avd_audio_window (48 bytes)
@@ -144,6 +144,7 @@ def load() -> C.CDLL:
     L.avd_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.avd_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.avd_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.avd_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.avd_debug_fetch.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.avd_debug_fetch.restype = C.c_int64
     for name in EXPORTS:
@@ -540,6 +541,18 @@ class Context:
             ms = C.c_float()
             self._check(self._L.avd_stage_ms(self._h, i, C.byref(ms)))
             out.append(float(ms.value))
+        return out
+
+    KERNEL_IDS = ("preprocess", "hash", "pyramid", "polyexp", "level40", "flow_up80", "level80", "flow_up160", "level160",
+                  "flow_up320", "level320", "rerun", "stats", "records", "other")      # enum avd_kernel_id
+
+    def kernel_ms(self) -> dict:
+        """Per-kernel device time (ms) of the last drained call with profiling on (avd_kernel_ms)."""
+        out = {}
+        for i, name in enumerate(self.KERNEL_IDS):
+            ms = C.c_float()
+            self._check(self._L.avd_kernel_ms(self._h, i, C.byref(ms)))
+            out[name] = float(ms.value)
         return out
 
     def debug_fetch(self, name: str, shape, dtype) -> np.ndarray:

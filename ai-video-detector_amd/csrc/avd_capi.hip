@@ -315,6 +315,7 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
         if (into_records) {
             // frames p0 + 1 .. p0 + np, and frame 0 with the first chunk
             const int fa = p0 == 0 ? 0 : p0 + 1;
+            kmark(ctx, AVD_K_RECORDS);
             hipLaunchKernelGGL(k_records, dim3(p0 + np + 1 - fa), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap,
                                (const uint8_t*)ws.d_hash, (const float*)ws.d_stats,
                                (const int*)(ctx->fb_mode == 1 && ctx->fb_rerun ? ws.d_fbflags : nullptr), p0, ws.d_rec, fa, records_clipstart, 1);
@@ -415,6 +416,7 @@ static void impl_destroy(avd_ctx* ctx)
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kern_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->kmark_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -545,6 +547,7 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
         ws.stage_bytes = stage_bytes;
     }
     // pass 2: per clip, stage (host input) -> fused full-resolution kernel -> hash / Hamming, at the clip's offsets
+    ctx->kmark_used = 0;
     stage_mark(ctx, 0);
     int f0 = 0;
     size_t rb = 0, lp = 0, st = 0;
@@ -559,6 +562,7 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
         const size_t sb = clip_stage_bytes(k, &coff);
         const uint8_t* d_in = k.data;
         const uint8_t* d_uv = k.uv;
+        kmark(ctx, AVD_K_PREPROCESS);
         if (k.mem == AVD_MEM_HOST) {
             uint8_t* dst = ws.d_stage + st;
             if (!k.uv) {
@@ -582,12 +586,14 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
             build_yuv_consts(nv.k);
             if (int e = launch_preprocess_nv12(ctx, d_in, nv, k.n, k.h, k.w, k.row_stride, k.frame_stride)) return e;
         }
+        kmark(ctx, AVD_K_HASH);
         if (int e = launch_hash(ctx, k.n, false)) return e;
         f0 += k.n;
         rb += rowbuf_elems_for(ws, k.n);
         lp += lappart_elems_for(ws, k.n);
     }
     ws.f0 = 0; ws.rowbuf_off = 0; ws.lappart_off = 0;
+    kmark(ctx, AVD_K_OTHER);
     stage_mark(ctx, 1);
     const int* clipstart = nullptr;                        // one clip: frame 0 is the only one without a predecessor
     if (nclips > 1) {
@@ -599,11 +605,13 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
         hipLaunchKernelGGL(k_records, dim3(n), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap, (const uint8_t*)ws.d_hash,
                            (const float*)nullptr, (const int*)nullptr, 0, ws.d_rec, 0, clipstart, 0);
     else if (int e = run_flow_chunks(ctx, ws.d_small, n, nullptr, nullptr, nullptr, true, clipstart)) return e;
+    kmark(ctx, AVD_K_OTHER);
     stage_mark(ctx, 3);
     // into PINNED memory: a device-to-host copy into the caller's pageable buffer would block this thread until
     // the whole call is done and it would not be asynchronous at all; avd_synchronize hands the records over
     HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pending_out = records; ctx->pending_n = n;
+    kmark(ctx, AVD_K_COUNT);                               // end of the last region
     stage_mark(ctx, 4);
     ctx->last_n = n;
     ctx->rec_n = n;
@@ -692,6 +700,15 @@ static int impl_synchronize(avd_ctx* ctx)
         for (int i = 0; i < ctx->pending_n; i++) ctx->last_rerun += ctx->ws.h_rec[i].reserved != 0;
         ctx->pending_out = nullptr; ctx->pending_n = 0;
     }
+    if (ctx->profiling && ctx->kmark_used > 1) {
+        for (float& v : ctx->kernel_ms) v = 0.f;
+        for (int i = 0; i + 1 < ctx->kmark_used; i++) {
+            float ms = 0.f;
+            if (ctx->kmark_id[i] < AVD_K_COUNT && hipEventElapsedTime(&ms, ctx->kmark_ev[i], ctx->kmark_ev[i + 1]) == hipSuccess)
+                ctx->kernel_ms[ctx->kmark_id[i]] += ms;
+        }
+    }
+    ctx->kmark_used = 0;
     if (ctx->profiling && ctx->stage_marks == 5) {
         // stages: 0 preprocess, 1 hash+hamming+records, 2 farneback+stats (3 reported as copy-out)
         for (int i = 0; i < 4; i++) {
@@ -745,6 +762,13 @@ static int impl_stage_ms(avd_ctx* ctx, int stage, float* ms)
 {
     if (!ctx || !ms || stage < 0 || stage > 5) return AVD_ERR_ARG;
     *ms = ctx->stage_ms[stage];
+    return AVD_OK;
+}
+
+static int impl_kernel_ms(avd_ctx* ctx, int id, float* ms)
+{
+    if (!ctx || !ms || id < 0 || id >= AVD_K_COUNT) return AVD_ERR_ARG;
+    *ms = ctx->kernel_ms[id];
     return AVD_OK;
 }
 
@@ -1215,6 +1239,7 @@ int avd_set_option(avd_ctx* ctx, const char* name, int value) { return guarded(c
 int avd_get_option(avd_ctx* ctx, const char* name, int* value) { return guarded(ctx, [&] { return impl_get_option(ctx, name, value); }); }
 int avd_set_profiling(avd_ctx* ctx, int enable) { return guarded(ctx, [&] { return impl_set_profiling(ctx, enable); }); }
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms) { return guarded(ctx, [&] { return impl_stage_ms(ctx, stage, ms); }); }
+int avd_kernel_ms(avd_ctx* ctx, int kernel_id, float* ms) { return guarded(ctx, [&] { return impl_kernel_ms(ctx, kernel_id, ms); }); }
 
 int64_t avd_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_t out_bytes)
 {

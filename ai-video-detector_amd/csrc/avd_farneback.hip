@@ -1022,6 +1022,7 @@ void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int
 {
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
     const int wgs = n * (PyrGeo<0>::TILES + PyrGeo<1>::TILES + PyrGeo<2>::TILES + PyrGeo<3>::TILES);
+    kmark(ctx, AVD_K_PYRAMID);
     hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3], g.flags);
     PolyPtrs P;
     int grid = ((n * (S / kPolyRows) + 7) >> 3) << 3;      // the 320-px scale: kPolyRows rows per workgroup
@@ -1029,6 +1030,7 @@ void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int
         P.I[k] = g.pyr[k]; P.R[k] = g.poly[k];
         if (k > 0) grid += ((n * (S >> (2 * k)) + 7) >> 3) << 3;
     }
+    kmark(ctx, AVD_K_POLYEXP);
     hipLaunchKernelGGL(k_polyexp_all, dim3(grid), dim3(320), 0, g.stream, P, n, C);
 }
 
@@ -1087,11 +1089,13 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         } else {
             const int items = np * 2 * h * (w / 4);
             const float* prev = ctx->ws.flow_res[k + 1];
+            kmark(ctx, k == 2 ? AVD_K_FLOWUP80 : (k == 1 ? AVD_K_FLOWUP160 : AVD_K_FLOWUP320));
             if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
             else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
             else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
         }
         ctx->ws.flow_res[k] = g.flow[k];
+        kmark(ctx, k == 3 ? AVD_K_LEVEL40 : (k == 2 ? AVD_K_LEVEL80 : (k == 1 ? AVD_K_LEVEL160 : AVD_K_LEVEL320)));
         if (ctx->fb_mode == 1) {
             // fast level kernel (avd_fbfast.hip): one launch per iteration, the flow ping-pongs between the level's two buffers
             float* a = g.flow[k];
@@ -1112,6 +1116,7 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
                 // statistics read them
                 float* fl[4] = {a, g.flow[1], g.flow[2], g.flow[3]};
                 const float* Rk[4] = {g.poly[0], g.poly[1], g.poly[2], g.poly[3]};
+                kmark(ctx, AVD_K_RERUN);
                 if (int e = launch_fb_rerun(ctx, stream, Rk, fl, ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX, g.flags, np)) return e;
             }
             continue;
@@ -1145,6 +1150,7 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
     const int np = n - 1;
     const float* fl = ctx->ws.flow_res[0] ? ctx->ws.flow_res[0] : g.flow[0];
     float* mg = ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX;
+    kmark(ctx, AVD_K_STATS);
     if (!ctx->ws.mag_valid) launch1d(k_mag, (int64_t)np * (AVD_NPIX / 4), 256, stream, fl, mg, (int64_t)np * (AVD_NPIX / 4));
     hipLaunchKernelGGL(k_stats_pair, dim3(np), dim3(512), 0, stream, (const float*)mg, g.stats);
     if (g.flow_il)

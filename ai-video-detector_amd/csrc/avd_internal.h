@@ -161,6 +161,12 @@ struct avd_ctx {
     int kern_ev_used = 0;
     int profiling = 0;
     int stage_marks = 0;                       // stage events recorded by the call in flight (5 = all of them)
+    // per-kernel profiling (avd_kernel_ms): an event in front of every kernel (group) of the path, labelled with the avd_kernel_id of the
+    // region that starts there; elapsed times between consecutive events are summed per id when the call is drained
+    hipEvent_t kmark_ev[96] = {};
+    int kmark_id[96] = {};
+    int kmark_used = 0;
+    float kernel_ms[AVD_K_COUNT] = {};
     float stage_ms[6] = {};
     std::string err;
     Workspace ws;
@@ -179,6 +185,15 @@ struct avd_ctx {
     int fb_rerun = 1;               // fast mode: pairs the level kernel flags as ill-posed are re-run by the exact kernels (k_fb_rerun); 0 = A/B, tests
     int last_rerun = 0;             // pairs re-run by the last drained call
 };
+
+// profiling only (avd_set_profiling): the region that starts here on the context's stream is kernel `id`
+inline void kmark(avd_ctx* ctx, int id)
+{
+    if (!ctx->profiling || ctx->kmark_used >= 96) return;
+    hipEvent_t& e = ctx->kmark_ev[ctx->kmark_used];
+    if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; return; }
+    if (hipEventRecord(e, ctx->stream) == hipSuccess) ctx->kmark_id[ctx->kmark_used++] = id;
+}
 
 template <typename T>
 inline int dev_alloc(avd_ctx* ctx, T*& p, size_t count)

@@ -53,7 +53,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 FP32_VALU_PEAK_TF = 157.3
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")      # HBM bytes per launch from rocprofv3 --pmc passes (fast mode)
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json"))
+                 if os.path.exists(f)), os.path.join(ROOT, "profiles", "r03_pmc.json"))      # rocprofv3 --pmc passes of the fast mode
 PMC_FILE_EXACT = os.path.join(ROOT, "profiles", "r02_pmc.json")
 FP64_VALU_PEAK_TF = 78.6
 
@@ -166,6 +167,86 @@ def roofline_objects(n, h, w, stage, latency_ms, mode="fast", ops=None):
           "pixels_per_pair_all_levels": px,
           "traffic": pmc.get("farneback_stage", {}).get("hbm_bytes")}
     return dominant, pre, fb
+
+
+def kernel_table(n, h, w, kms, nv12_ms=None):
+    """roofline.kernels: every kernel (group) of one clip with its ALGORITHMIC bytes priced against the HBM peak and its
+    measured duration (avd_kernel_ms: HIP events on the library's stream, clips run alone, mean over the exclusive pass).
+    A level's row is the sum of its launches.  `bound` says what the kernel is limited by, which for everything but the
+    full-resolution pass is NOT the HBM bandwidth (the fraction shows how far from it): the level kernels by VALU issue + the
+    texture-addresser path of the bilinear gathers (320 px) or by the latency of 16 .. 44 barrier steps (smaller levels),
+    the polynomial expansion by VALU issue (cv2's double accumulators)."""
+    np_ = max(n - 1, 0)
+    px = {320: 320 * 320, 160: 160 * 160, 80: 80 * 80, 40: 40 * 40}
+    allpx = sum(px.values())
+    lvl = lambda ww, first_quarter: 3 * (n * px[ww] * 20 + np_ * px[ww] * 16) - (np_ * (px[ww] - px[ww] // 4) * 8 if first_quarter else 0)  # noqa: E731
+    rows = [
+        ("preprocess", "hbm", n * preprocess_bytes_per_frame(h, w), kms.get("preprocess"), 1),
+        ("hash", "latency", n * (h * 32 * 4 + 2048), kms.get("hash"), 1),
+        ("pyramid", "latency+lds", n * (px[320] + 4 * allpx), kms.get("pyramid"), 1),
+        ("polyexp", "valu", n * allpx * 24, kms.get("polyexp"), 1),
+        ("level40", "latency", lvl(40, False), kms.get("level40"), 3),
+        ("flow_up80", "latency", np_ * (px[40] + px[80]) * 8, kms.get("flow_up80"), 1),
+        ("level80", "latency", lvl(80, False), kms.get("level80"), 3),
+        ("flow_up160", "latency", np_ * (px[80] + px[160]) * 8, kms.get("flow_up160"), 1),
+        ("level160", "latency", lvl(160, False), kms.get("level160"), 3),
+        ("flow_up320", "hbm", np_ * (px[160] + px[320]) * 8, kms.get("flow_up320"), 1),
+        ("level320", "valu+ta", lvl(320, not kms.get("flow_up320")), kms.get("level320"), 3),
+        ("rerun", "launch", 0, kms.get("rerun"), 1),
+        ("stats", "latency", np_ * px[320] * 4, kms.get("stats"), 1),
+        ("records", "launch", n * 2080, kms.get("records"), 1),
+    ]
+    if nv12_ms:
+        rows.append(("nv12_ingest (instead of preprocess)", "valu", n * (h * w * 3 // 2 + 320 * 320 + 1024 + 16), nv12_ms, 1))
+    out = []
+    for name, bound, alg, ms, launches in rows:
+        if not ms or ms <= 0:
+            continue
+        out.append({"name": name, "bound": bound, "us": round(ms * 1e3, 1), "launches": launches,
+                    "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alg else None})
+    return out
+
+
+def compact_line(full, details_path=None):
+    """The ONE JSON line rank 0 prints: the driver's contract keys, the roofline of the dominant kernel with the per-kernel
+    table, cpu_baseline, and one figure per extra; everything else (notes, sub-objects) goes to --details FILE."""
+    pick = lambda d, keys: {k: d[k] for k in keys if d is not None and k in d}  # noqa: E731
+    line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    line["config"] = pick(full["config"], ("workload", "frames_per_clip", "height", "width", "clips_per_step", "clips_in_flight_per_gpu",
+                                           "fb_mode", "sec_per_video", "sec_per_video_resident", "sec_per_video_nv12", "parallelism"))
+    line["repeats"] = pick(full.get("repeats"), ("n", "statistic", "value_min", "value_max"))
+    r = full["roofline"]
+    line["roofline"] = pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_from_profiles",
+                                "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "share_of_step", "limiter",
+                                "frac_of_vector_peak", "valu_issue_frac_from_profiles", "ta_busy_frac_from_profiles", "kernels",
+                                "whole_step_frac", "preprocess_frac", "timed"))
+    if full.get("cpu_baseline"):
+        line["cpu_baseline"] = pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "single_thread_value", "cores_usable_how"))
+    else:
+        line["cpu_baseline"] = None
+    if full.get("fb_modes"):
+        line["fb_modes"] = pick(full["fb_modes"], ("value_uses", "rerun_pairs", "guarantee", "exact_frames_per_s", "fast_without_rerun_frames_per_s",
+                                                   "exact_level320_ms"))
+    ext = {}
+    for key, short in (("mfma_patch_embed", "patch_embed"), ("mfma_cnn_forward", "cnn_forward"), ("layernorm_tokens", "layernorm"),
+                       ("roofline_nv12_ingest", "nv12_ingest")):
+        if full.get(key):
+            ext[short] = pick(full[key], ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "forward_ms", "hbm_traffic_bytes_per_forward"))
+    if full.get("audio_analyzer"):
+        ext["audio"] = pick(full["audio_analyzer"], ("gpu_call_ms", "windows"))
+    if ext:
+        line["extensions"] = ext
+    for key in ("pcie_inclusive_fps", "pcie_inclusive_fps_one_clip_at_a_time"):
+        if key in full:
+            line[key] = full[key]
+    for key in ("short_clips_fps", "mixed_stream_fps"):
+        if full.get(key):
+            line[key] = pick(full[key], ("value", "one_clip_per_call"))
+    line["result_check"] = full.get("result_check")
+    if details_path:
+        line["details"] = details_path
+    return line
 
 
 _CPU_CHILD = r"""
@@ -312,6 +393,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-mode pass and the short-clip / mixed-stream batches")
     ap.add_argument("--launch-check", action="store_true", help="multi-rank plumbing check without a GPU (gloo); not a measurement")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--details", default=None, metavar="FILE",
+                    help="also write the verbose record (every sub-object and note behind the printed line) to FILE")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
     ap.add_argument("--no-vit", action="store_true", help="skip the extensions reported apart (ViT patch-embed GEMM, CNN forward, audio analyzer)")
     ap.add_argument("--pcie", action="store_true", help="accepted for compatibility (the PCIe-inclusive figures are on by default)")
@@ -338,6 +421,12 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if args.launch_check:
         sys.exit(launch_check(args, rank, world))
+
+    # stdout carries exactly ONE line, rank 0's JSON record: whatever a library (RCCL, gloo, a compiler run by build()) writes to
+    # file descriptor 1 in any rank goes to stderr instead; the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     n, h, w = args.frames, args.height, args.width
     meta = {"width": w, "height": h, "fps": 30.0, "duration": n / 2.0}
@@ -475,12 +564,17 @@ def main():
         retire()
     lat, excl = [], np.zeros(6)
     n_excl = 10
+    kms = {}                                # per-kernel device times of a clip run alone (avd_kernel_ms), mean of the pass
     for _ in range(n_excl):
         stage[:] = 0
         submit(0)
         retire()
         excl += stage
+        for kk, vv in ctxs[0].kernel_ms().items():
+            kms[kk] = kms.get(kk, 0.0) + vv / n_excl
     excl /= n_excl
+    rerun_pairs = ctxs[0].get_option("rerun_pairs")
+    fb_mode_used = {0: "exact", 1: "fast+rerun" if ctxs[0].get_option("fb_rerun") else "fast (re-run off)"}[ctxs[0].get_option("fb_mode")]
     set_prof(False)                   # from here on nothing but the work itself is on the streams
     submit(0)
     retire()
@@ -746,19 +840,29 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fps = lambda e: world * n * args.steps / e          # noqa: E731
-        dominant, pre, fb = roofline_objects(n, h, w, excl, latency_ms, "fast", ops)
+        dominant, pre, fb = roofline_objects(n, h, w, excl, latency_ms, "exact" if fb_mode_used == "exact" else "fast", ops)
+        pmc_k = load_pmc().get("k_fb_level<320>" if fb_mode_used == "exact" else "k_fb_fast<320>", {}) if (n, h, w) == (120, 1080, 1920) else {}
+        dominant["traffic_from_profiles"] = os.path.relpath(PMC_FILE, ROOT) if dominant.get("traffic") is not None else None
+        dominant["limiter"] = ("not HBM: VALU issue of the normal equations + the texture-addresser / L1 path of the bilinear gathers + one "
+                               "workgroup barrier per 4-row step (PMC fractions beside; `frac` prices the algorithmic bytes against the HBM peak)")
+        dominant["valu_issue_frac_from_profiles"] = pmc_k.get("valu_issue_frac")
+        dominant["ta_busy_frac_from_profiles"] = pmc_k.get("ta_busy_frac")
+        dominant["frac_of_vector_peak"] = (dominant.get("valu") or {}).get("frac_of_vector_peak")
+        dominant["preprocess_frac"] = pre["frac"]
+        dominant["kernels"] = kernel_table(n, h, w, kms, None if nv12 is None else nv12["pre_ms"])
         out = {
             "metric": "sampled frames/sec analysed (1080p30 60 s clip, 2 fps sampling)",
             "value": round(fps(elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 pixels; f32/f64 Farneback (cv2's own types)",
-            "data": "synthetic", "fb_mode_used": "fast",
+            "data": "synthetic", "fb_mode_used": fb_mode_used,
             "repeats": {"n": len(elapsed_all), "statistic": "median", "value_min": round(fps(max(elapsed_all)), 2),
                         "value_max": round(fps(min(elapsed_all)), 2),
                         "ms_per_step_min": round(min(elapsed_all) / args.steps * 1e3, 4),
                         "ms_per_step_max": round(max(elapsed_all) / args.steps * 1e3, 4)},
             "config": {"workload": "BASELINE.json configs[1]: 1080p30 60 s clip, 2 fps sampling, one clip per GPU per step",
                        "frames_per_clip": n, "height": h, "width": w, "clips_per_step": world, "clips_in_flight_per_gpu": m,
+                       "fb_mode": fb_mode_used,
                        "input_copies_in_hbm": m,
                        "sec_per_video": round((host_lat_ms if host_lat_ms is not None else latency_ms) / 1e3, 6),
                        "sec_per_video_note": ("one clip alone, from decoded frames in pinned host memory to the fused result "
@@ -795,7 +899,8 @@ def main():
                 "what": "all kernels of one clip (preprocess, hash, pyramid, polynomial expansion, 4 level kernels, flow_up, statistics)",
                 "bound": "hbm", "traffic": whole, "algorithmic_bytes_input_only": preprocess_bytes_per_frame(h, w) * n,
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "note": "PMC HBM traffic per clip (profiles/r03_pmc.json) / ms_per_step with clips in flight"}
+                "note": "PMC HBM traffic per clip (traffic replayed from " + os.path.relpath(PMC_FILE, ROOT) + ") / ms_per_step with clips in flight"}
+            out["roofline"]["whole_step_frac"] = out["roofline_whole_step"]["frac"]
         if pcie_fps is not None:
             out["pcie_inclusive_fps"] = round(pcie_fps_inflight if pcie_fps_inflight is not None else pcie_fps, 1)
             out["pcie_inclusive_fps_one_clip_at_a_time"] = round(pcie_fps, 1)
@@ -867,8 +972,11 @@ def main():
         if exact is not None:
             edom, _, efb = roofline_objects(n, h, w, exact["stage"], exact["latency_ms"], "exact", ops)
             out["fb_modes"] = {
-                "value_uses": "fast",
-                "fast": {"what": "csrc/avd_fbfast.hip: flow identical to the oracle on well-posed inputs, within 1e-5 px / ai_susp 1e-6 (tests/test_gpu_fbfast.py)",
+                "value_uses": fb_mode_used, "rerun_pairs": rerun_pairs,
+                "guarantee": "flagged (ill-posed) pairs re-run by the exact kernels: bit-identical; others flow <= 1e-5 px, flow_mean/var rel 1e-6, "
+                             "ai_susp 1e-6 (tests/test_gpu_fbfast.py, tests/test_gpu_soak.py)",
+                "exact_frames_per_s": round(exact["fps"], 2), "exact_level320_ms": round(float(exact["stage"][4]), 4),
+                "fast": {"what": "csrc/avd_fbfast.hip + k_fb_rerun: flow identical to the oracle on well-posed inputs (<= 1e-5 px), ill-posed pairs re-run exactly",
                          "frames_per_s": out["value"], "sec_per_video_resident": round(latency_ms / 1e3, 6),
                          "level0_all_iterations_ms": round(float(excl[4]), 4), "farneback_and_flow_stats_ms": round(float(excl[2]), 4),
                          "flow_mean_head": [float(v) for v in recs[0]["flow_mean"][1:4]]},
@@ -888,9 +996,15 @@ def main():
                             "(cached geometry tables, nothing allocated in steady state; the Farneback stage batches uniformly at 320 x 320)",
                 "value": round(batches["mixed"][0], 1), "unit": "frames/s",
                 "one_clip_per_call": round(batches["mixed"][1], 1)}
+        if "fb_modes" not in out:
+            out["fb_modes"] = {"value_uses": fb_mode_used, "rerun_pairs": rerun_pairs}
         out["ops"] = ops
         out["cpu_baseline"] = cpu_base
-        print(json.dumps(out))
+        if args.details:
+            with open(args.details, "w") as fh:
+                json.dump(out, fh, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(compact_line(out, args.details)) + "\n").encode())
     if use_dist:
         tdist.destroy_process_group()
 

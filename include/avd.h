@@ -279,6 +279,22 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
 int avd_set_option(avd_ctx* ctx, const char* name, int value);
 int avd_get_option(avd_ctx* ctx, const char* name, int* value);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
+/* Per-kernel device time (ms) of the LAST drained avd_analyze_* call with profiling on: HIP events on the context's stream in
+ * front of every kernel (group) of the path; a level's figure is the sum of its launches (fast mode: three, one per blur
+ * iteration).  bench.py's roofline.kernels is built from these, with clips run alone. */
+enum avd_kernel_id {
+    AVD_K_PREPROCESS = 0,  /* k_preprocess_vec / k_preprocess_nv12 (+ staging copies of host input) */
+    AVD_K_HASH,            /* k_hash: 32 x 32 INTER_AREA cells, mean threshold, moment reduction */
+    AVD_K_PYRAMID,         /* k_pyramid_all: Gaussian blur + decimation, four scales */
+    AVD_K_POLYEXP,         /* k_polyexp_all: polynomial expansion, four scales */
+    AVD_K_LEVEL40, AVD_K_FLOWUP80, AVD_K_LEVEL80, AVD_K_FLOWUP160, AVD_K_LEVEL160, AVD_K_FLOWUP320, AVD_K_LEVEL320,
+    AVD_K_RERUN,           /* k_fb_rerun: exact re-run of the pairs flagged ill-posed (returns at once when none is) */
+    AVD_K_STATS,           /* k_stats_pair (exact mode: + k_mag) */
+    AVD_K_RECORDS,         /* k_records: Hamming distances, record assembly */
+    AVD_K_OTHER,           /* clip-table upload, records copy-out */
+    AVD_K_COUNT
+};
+int avd_kernel_ms(avd_ctx* ctx, int kernel_id, float* ms);
 
 /* Test hook: copy an internal device buffer of the last call to host.
  * name: "area" uint8[n][1024]; "pyr<L>" float[n][hL][wL]; "poly<L>" float[n][hL][wL][5];

@@ -108,7 +108,77 @@ def test_cli_defaults_are_the_driver_contract():
     for flag, default in (("--gpus", "1"), ("--steps", "20"), ("--warmup", "3"), ("--inflight", "3"), ("--repeats", "25"),
                           ("--cpu-procs", "0")):
         assert re.search(r'add_argument\("%s", type=int, default=%s' % (re.escape(flag), default), src), flag
-    # one JSON line on stdout, printed by rank 0 only
-    assert src.count("print(json.dumps(out))") == 1
+    # one JSON line on stdout, written by rank 0 only, to the descriptor saved before fd 1 was pointed at stderr
+    assert src.count("os.write(real_stdout, (json.dumps(compact_line(out, args.details))") == 1
+    assert src.index("os.dup2(2, 1)") < src.index("    import avd_hip\n")
     # the CPU baseline and the self-launch come before the first GPU-related import
     assert src.index("sys.exit(self_launch(args))") < src.index("cpu_base = cpu_baseline(") < src.index("    import avd_hip\n")
+
+
+def _verbose_sample(b):
+    """A verbose record with every key bench.py emits, long notes included (what --details FILE receives)."""
+    stage = [0.158, 0.005, 0.93, 0.006, 0.435, 0.0]
+    ops = {"level0_three_iterations_per_pair": {"f32": 25_200_000, "f64": 10_200_000}, "per_pair_as_cv2": {"f32": 80_000_000, "f64": 32_000_000}}
+    dom, pre, fb = b.roofline_objects(120, 1080, 1920, stage, latency_ms=1.15, mode="fast", ops=ops)
+    kms = {"preprocess": 0.158, "hash": 0.008, "pyramid": 0.052, "polyexp": 0.12, "level40": 0.033, "flow_up80": 0.005, "level80": 0.074,
+           "flow_up160": 0.012, "level160": 0.141, "flow_up320": 0.0, "level320": 0.435, "rerun": 0.003, "stats": 0.019, "records": 0.004, "other": 0.01}
+    dom.update({"traffic_from_profiles": "profiles/r04_pmc.json", "limiter": "x" * 300, "valu_issue_frac_from_profiles": 0.55,
+                "ta_busy_frac_from_profiles": 0.53, "frac_of_vector_peak": 0.16, "preprocess_frac": pre["frac"], "whole_step_frac": 0.42,
+                "kernels": b.kernel_table(120, 1080, 1920, kms, 0.26)})
+    note = "n" * 400
+    full = {"metric": "sampled frames/sec analysed (1080p30 60 s clip, 2 fps sampling)", "value": 126000.0, "unit": "frames/s", "n_gpus": 1,
+            "steps": 20, "warmup": 3, "ms_per_step": 0.95, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 pixels; f32/f64 Farneback (cv2's own types)", "data": "synthetic", "fb_mode_used": "fast+rerun",
+            "repeats": {"n": 25, "statistic": "median", "value_min": 1.0, "value_max": 2.0, "ms_per_step_min": 1.0, "ms_per_step_max": 2.0},
+            "config": {"workload": "BASELINE.json configs[1]: 1080p30 60 s clip, 2 fps sampling, one clip per GPU per step", "frames_per_clip": 120,
+                       "height": 1080, "width": 1920, "clips_per_step": 1, "clips_in_flight_per_gpu": 3, "fb_mode": "fast+rerun", "sec_per_video": 0.0147,
+                       "sec_per_video_note": note, "sec_per_video_nv12": 0.0083, "sec_per_video_resident": 0.00115, "parallelism": "single GPU"},
+            "roofline": dom, "roofline_preprocess": pre, "roofline_farneback_stage": fb, "stages_ms": {"note": note}, "ops": ops,
+            "cpu_baseline": {"value": 453.0, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "s" * 200, "single_thread_value": 30.7,
+                             "process_ladder": [{"procs": 16, "frames_per_s": 453.0}] * 4, "cores_usable_how": "cgroup CPU quota 16"},
+            "fb_modes": {"value_uses": "fast+rerun", "rerun_pairs": 0, "guarantee": "g" * 200, "exact_frames_per_s": 110000.0, "exact_level320_ms": 0.84,
+                         "fast": {"what": note}, "exact": {"what": note, "roofline": dict(dom)}},
+            "mfma_patch_embed": {"kernel": note, "bound": "mfma", "achieved": 880.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.35, "avg_launch_ms": 0.25},
+            "mfma_cnn_forward": {"kernel": note, "bound": "mfma", "achieved": 407.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.163, "forward_ms": 2.4,
+                                 "hbm_traffic_bytes_per_forward": 7_610_000_000, "hbm_note": note},
+            "layernorm_tokens": {"kernel": note, "bound": "hbm", "achieved": 4740.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.59, "avg_launch_ms": 0.122},
+            "roofline_nv12_ingest": {"kernel": note, "bound": "hbm", "achieved": 1600.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.2, "avg_launch_ms": 0.26},
+            "audio_analyzer": {"what": note, "gpu_call_ms": 0.58, "windows": 120}, "pcie_inclusive_fps": 9000.0, "pcie_inclusive_fps_one_clip_at_a_time": 8000.0,
+            "short_clips_fps": {"workload": note, "value": 124000.0, "unit": "frames/s", "one_clip_per_call": 73000.0},
+            "mixed_stream_fps": {"workload": note, "value": 108000.0, "unit": "frames/s", "one_clip_per_call": 67000.0},
+            "result_check": {"ai_timeline_head": [0.1, 0.2, 0.3], "dup_density": 0.09, "label": "uncertain", "ai_score": 0.45, "confidence": 0.1, "reason": "r" * 80}}
+    return full
+
+
+def test_the_printed_line_is_compact_and_keeps_what_the_driver_reads():
+    """the driver's record cut a 15-KB line.  The printed line stays below 8 KB whatever the verbose record
+    holds, keeps the contract keys, `roofline` with the per-kernel table and PMC-derived fractions named *_from_profiles, and
+    `cpu_baseline`; everything else goes to --details FILE."""
+    import json
+    b = _bench()
+    full = _verbose_sample(b)
+    line = b.compact_line(full, "gpurun_out/details.json")
+    text = json.dumps(line)
+    assert len(text) < 8192, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert r["traffic_from_profiles"] and r["valu_issue_frac_from_profiles"] == 0.55 and r["ta_busy_frac_from_profiles"] == 0.53
+    names = [k["name"] for k in r["kernels"]]
+    for want in ("preprocess", "pyramid", "polyexp", "level40", "level80", "level160", "level320", "stats"):
+        assert want in names, want
+    assert any(nm.startswith("nv12") for nm in names)
+    for k in r["kernels"]:
+        assert set(k) == {"name", "bound", "us", "launches", "frac"} and k["us"] > 0
+    lvl = next(k for k in r["kernels"] if k["name"] == "level320")
+    assert abs(lvl["frac"] - r["frac"]) < 0.01                       # the dominant kernel's row agrees with the roofline object
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 16 and "process_ladder" not in line["cpu_baseline"]
+    assert line["fb_modes"]["rerun_pairs"] == 0 and line["config"]["workload"].startswith("BASELINE.json configs[1]")
+    assert line["extensions"]["patch_embed"]["frac"] == 0.35 and "kernel" not in line["extensions"]["patch_embed"]
+    # N > 1: no cpu_baseline (rank 0 at N = 1 only), the roofline stays
+    full["cpu_baseline"] = None
+    full["n_gpus"] = 8
+    l8 = b.compact_line(full)
+    assert l8["cpu_baseline"] is None and l8["roofline"]["kernels"] and "details" not in l8
