@@ -213,6 +213,67 @@ __device__ __forceinline__ void ne_finish_r(const NeIn& in, const NeG2& g, int x
     r[0] = r2; r[1] = r3; r[2] = r4; r[3] = r5; r[4] = r6;
 }
 
+// ---- neighbour-shared gather (round 4, fast level kernel at 320 px) ------------------------------------------------
+// The bilinear footprint of a lane is pixels x1, x1 + 1 of rows y1, y1 + 1 of R1: 4 x 20 bytes, and where the flow is smooth
+// lane l + 1's LEFT pixel is lane l's RIGHT one.  A lane therefore loads only its left pixel (both rows: 40 bytes instead
+// of 80 through the texture-addresser / L1 path, which limits this kernel) and takes the right one from lane l + 1 with a
+// DPP wave shift when that lane's clamped position is exactly (x1 + 1, y1); lanes for which it is not (the floor of x + dx
+// does not advance by one, another row, lane 63, clamped positions at the image edge) fetch their right pixel themselves
+// with loads that only they execute.  Same values from the same addresses as ne_gather2: bit-identical.
+typedef float flt4v __attribute__((ext_vector_type(4)));
+struct NeG3 { float lt[5], lb[5]; flt4v rt, rb; float rt4, rb4; int x1, y1; bool own; };   // left top / bottom; right top / bottom (own load, if `own`)
+
+__device__ __forceinline__ int dpp_from_next_lane(int v)      // lane l receives lane l + 1's value (lane 63: 0)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, false);      // wave_shl:1
+}
+
+// The own-lanes-only loads are BUFFER loads whose offset is out of range for every other lane (the hardware's range check
+// returns zero for those without touching memory): no divergent control flow -- as a divergent `if` the compiler merges the
+// loaded registers with the untaken path inside the block, behind an s_waitcnt for the loads just issued, and every entry
+// waits a full memory round trip (ISA: vmcnt(3) / vmcnt(2) right after the four loads) -- and no hand-counted waits.
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ne_gather3(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
+                                           int w, int h, int lane, NeG3& g, bool zf = false)
+{
+    const float fx = x + (zf ? 0.f : in.dx), fy = y + (zf ? 0.f : in.dy);
+    g.x1 = floor_f(fx); g.y1 = floor_f(fy);
+    const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
+    const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
+    const F4 t0 = ld_off<F4>(R, pb);
+    const float t1 = ld_off<float>(R, pb + 16u);
+    const F4 b0 = ld_off<F4>(R, qb);
+    const float b1 = ld_off<float>(R, qb + 16u);
+    g.lt[0] = t0.a; g.lt[1] = t0.b; g.lt[2] = t0.c; g.lt[3] = t0.d; g.lt[4] = t1;
+    g.lb[0] = b0.a; g.lb[1] = b0.b; g.lb[2] = b0.c; g.lb[3] = b0.d; g.lb[4] = b1;
+    const int key = y1 * w + x1;                                            // one comparison for both coordinates (x1 <= w - 2)
+    g.own = lane == 63 || dpp_from_next_lane(key) != key + 1;
+    // every offset into R is below 2 GiB (the largest expansion buffer is ~1 GiB): 0x80000000 is out of range
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+    const int po = g.own ? (int)(pb + 20u) : (int)0x80000000, qo = g.own ? (int)(qb + 20u) : (int)0x80000000;
+    const int4v u0 = __builtin_amdgcn_raw_buffer_load_b128(rs, po, 0, 0), v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, qo, 0, 0);
+    const int u4 = __builtin_amdgcn_raw_buffer_load_b32(rs, po + 16, 0, 0), v4 = __builtin_amdgcn_raw_buffer_load_b32(rs, qo + 16, 0, 0);
+    g.rt = __builtin_bit_cast(flt4v, u0); g.rb = __builtin_bit_cast(flt4v, v0);
+    g.rt4 = __builtin_bit_cast(float, u4); g.rb4 = __builtin_bit_cast(float, v4);
+}
+
+// the right-hand pixel: the neighbour's left one, or the lane's own load (K: see ne_gather3)
+template <int K>
+__device__ __forceinline__ void ne_share3(NeG3& g, NeG2& o)
+{
+    const float rt[5] = {g.rt.x, g.rt.y, g.rt.z, g.rt.w, g.rt4}, rb[5] = {g.rb.x, g.rb.y, g.rb.z, g.rb.w, g.rb4};
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float nt = __builtin_bit_cast(float, dpp_from_next_lane(__builtin_bit_cast(int, g.lt[c])));
+        const float nb = __builtin_bit_cast(float, dpp_from_next_lane(__builtin_bit_cast(int, g.lb[c])));
+        o.top[c] = g.lt[c]; o.bot[c] = g.lb[c];
+        o.top[5 + c] = g.own ? rt[c] : nt;
+        o.bot[5 + c] = g.own ? rb[c] : nb;
+    }
+    o.x1 = g.x1; o.y1 = g.y1;
+}
+
 __device__ __forceinline__ void ne_products(const float (&r)[5], float scale, float (&M)[5])
 {
     const float r2 = r[0] * scale, r3 = r[1] * scale, r4 = r[2] * scale, r5 = r[3] * scale, r6 = r[4] * scale;

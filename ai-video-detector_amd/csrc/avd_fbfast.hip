@@ -36,6 +36,7 @@
 // share an XCD's L2), the flow is read and written (16 B/px per pair): 441 MB at 320 px x 119 pairs.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "avd_internal.h"
 #include "avd_fb_device.h"
 
@@ -51,9 +52,10 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 // entries each per step, 4: one each); XPB solver waves per block (1: four columns per lane, 2: two columns per lane).
 // 2 + 1 + 1 waves per block is the throughput shape (320 px: the chip is full and total issue counts); 4 + 1 + 2 is the
 // latency shape for the small levels, where a launch is steps x the slowest wave of a step and most CUs are idle anyway.
-template <int W_, int NB_, int GD_ = 1, int NPB_ = 2, int XPB_ = 1>
+// SH: the bilinear gather shares pixels between neighbouring lanes (ne_gather3, avd_fb_device.h)
+template <int W_, int NB_, int GD_ = 1, int NPB_ = 2, int XPB_ = 1, int SH_ = 0>
 struct FGeo {
-    static constexpr int W = W_, NB = NB_, GD = GD_, NPB = NPB_, XPB = XPB_;
+    static constexpr int W = W_, NB = NB_, GD = GD_, NPB = NPB_, XPB = XPB_, SH = SH_;
     static constexpr int H = W;
     static constexpr int SW = 64 * NB;               // lane columns of a strip
     static constexpr int WPB = NPB + 1 + XPB;        // waves per block
@@ -125,7 +127,11 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     auto ent = [&](int i) { return 4 * (i / EPS) + EPS * k + (i % EPS); };  // this wave's i-th entry
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
-    NeG2 g[NGS];
+    typename std::conditional<Ge::SH != 0, NeG3, NeG2>::type g[NGS];
+    auto gather = [&](const NeIn& s, int row, auto& gs) __attribute__((always_inline)) {
+        if constexpr (Ge::SH != 0) ne_gather3(R, r1base, s, x, row, W, H, lane, gs, zf);
+        else ne_gather2(R, r1base, s, x, row, W, H, gs, zf);
+    };
     auto flow_of = [&](int row, NeIn& s) { const float* f = fring + (row & 15) * Ge::F_SLOT + lane; s.dx = f[0]; s.dy = f[64]; };
     auto load_in = [&](int row, NeIn& s) {
         if (UP) ne_load_r0(R, r0base, x, row, W, s);
@@ -139,7 +145,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
         for (int i = 0; i <= GD; i++) flow_of(row_of(ent(i)), in[i]);
     }
 #pragma unroll
-    for (int i = 0; i < GD; i++) ne_gather2(R, r1base, in[i], x, row_of(ent(i)), W, H, g[i], zf);
+    for (int i = 0; i < GD; i++) gather(in[i], row_of(ent(i)), g[i]);
     auto work = [&](int t, int q) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < EPS; j++) {
@@ -148,7 +154,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
             // refills first: the gather GD entries ahead goes into the slot the previous entry released, the inputs
             // NIS - 1 entries ahead into the slot of the entry before this one (rows beyond the image clamp to the last)
 #ifndef AVD_FBF_NOGATHER          // timing-only ablation builds (results are wrong)
-            ne_gather2(R, r1base, in[(ii + GD) % NIS], x, row_of(ent(i + GD)), W, H, g[(ii + GD) % NGS], zf);
+            gather(in[(ii + GD) % NIS], row_of(ent(i + GD)), g[(ii + GD) % NGS]);
 #endif
 #ifndef AVD_FBF_NOINLOAD
             load_in(row_of(ent(i + NIS - 1)), in[(ii + NIS - 1) % NIS]);
@@ -156,7 +162,17 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
             if (UP) flow_of(row_of(ent(i + GD + 1)), in[(ii + GD + 1) % NIS]);   // for the gather issued with the next entry
             __builtin_amdgcn_sched_barrier(0);
             float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies
-            ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
+            if constexpr (Ge::SH != 0) {
+                // loads issued (in program order) between this entry's gather and here: the inputs of that step and the gathers + inputs
+                // of the GD steps since (4 + 4 and 4 loads per entry; UP: 2 input loads).  Eight fewer are assumed, should the
+                // compiler have moved some of its loads across the assembly block
+                constexpr int KW = (UP ? 2 : 4) + GD * (8 + (UP ? 2 : 4)) - 8;
+                NeG2 full;
+                ne_share3<KW>(g[ii % NGS], full);
+                ne_finish_r(in[ii % NIS], full, x, e, W, H, a, zf);
+            } else {
+                ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
+            }
             float* dst = mring + (e & 7) * Ge::M_SLOT + lane;
 #pragma unroll
             for (int c = 0; c < 5; c++) dst[c * 64] = a[c];
@@ -506,7 +522,10 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
     if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
-    case 320: launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 160, zero_first, up); break;
+    case 320:
+        if (var == 2) launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);      // A/B: every lane gathers all four pixels
+        else launch_fast<FGeo<320, 3, 2, 2, 1, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);
+        break;
     case 160:
         if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
         else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
