@@ -523,8 +523,10 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
     case 320:
-        if (var == 2) launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);      // A/B: every lane gathers all four pixels
-        else launch_fast<FGeo<320, 3, 2, 2, 1, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);
+        // A/B (AVD_FB_VARIANT=2): neighbour-shared gathers -- bit-identical, 40 instead of 80 gathered bytes per lane and entry, but eight
+        // VMEM instructions instead of six and ~25 more VALU per entry: 164 us per launch against 142 (profiles/r04_experiments.md)
+        if (var == 2) launch_fast<FGeo<320, 3, 2, 2, 1, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);
+        else launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);
         break;
     case 160:
         if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
