@@ -1081,11 +1081,18 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
     for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
         const int w = S >> k, h = S >> k;
         const int64_t plane = (int64_t)w * h;
+        const bool fast = ctx->fb_mode == 1;
+        // fast mode, what is folded into the level's launches (ctx->fb_fold_up, bit mask; no effect on results): bit 0 the 320-px level's
+        // first launch resizes the previous flow itself (chain wave); bit 1 the 160- and 80-px levels' first launch does it in a prologue;
+        // bit 2 the 80- and 40-px levels run their three iterations in ONE launch (a pair is one workgroup there)
+        const bool fold_chain = fast && k == 0 && (ctx->fb_fold_up & 1);
+        const bool fold_pro = fast && (k == 1 || k == 2) && (ctx->fb_fold_up & 2);
+        const bool one_launch = fast && (k == 2 || k == 3) && (ctx->fb_fold_up & 4);
         if (k == AVD_FB_LEVELS - 1) {
             // the coarsest level starts from zero flow: the fused kernel is told so, the two-kernel path reads a cleared buffer
-            if (!((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
-        } else if (k == 0 && ctx->fb_mode == 1 && ctx->fb_fold_up) {
-            // fast mode, 320 px: the first launch of the level resizes the previous level's flow on the fly (avd_fbfast.hip, UP)
+            if (!fast && !((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
+        } else if (fold_chain || fold_pro) {
+            // the level's first launch forms its initial flow from the previous level's (avd_fbfast.hip)
         } else {
             const int items = np * 2 * h * (w / 4);
             const float* prev = ctx->ws.flow_res[k + 1];
@@ -1096,28 +1103,37 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         }
         ctx->ws.flow_res[k] = g.flow[k];
         kmark(ctx, k == 3 ? AVD_K_LEVEL40 : (k == 2 ? AVD_K_LEVEL80 : (k == 1 ? AVD_K_LEVEL160 : AVD_K_LEVEL320)));
-        if (ctx->fb_mode == 1) {
-            // fast level kernel (avd_fbfast.hip): one launch per iteration, the flow ping-pongs between the level's two buffers
+        if (fast) {
+            // fast level kernel (avd_fbfast.hip): the flow ping-pongs between the level's two buffers, a = initial flow, results b, a, b
             float* a = g.flow[k];
             float* b = ctx->ws.d_flow2[k] + (size_t)pair_off * 2 * plane;
+            int* fl = ctx->fb_rerun ? g.flags : nullptr;
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            const bool up = k == 0 && ctx->fb_fold_up;
-            for (int it = 0; it < 3; it++) {
-                float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
-                const float* in = (up && it == 0) ? ctx->ws.flow_res[k + 1] : a;
-                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], in, b, mag, ctx->fb_rerun ? g.flags : nullptr, np, k == AVD_FB_LEVELS - 1 && it == 0, up && it == 0)) return e;
-                float* t = a; a = b; b = t;
+            const bool prev_in = fold_chain || fold_pro;                     // the first launch reads the previous level's flow
+            const float* prev = prev_in ? ctx->ws.flow_res[k + 1] : nullptr;
+            if (one_launch) {
+                // all three iterations in one launch: (prologue: prev -> a,) a -> b -> a -> b
+                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], prev_in ? prev : a, b, a, nullptr, fl, np, k == AVD_FB_LEVELS - 1, prev_in ? 4 : 3)) return e;
+                a = b;
+            } else {
+                for (int it = 0; it < 3; it++) {
+                    float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
+                    const bool first_prev = prev_in && it == 0;
+                    const int mode = !first_prev ? 0 : (fold_chain ? 1 : 2);
+                    if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], first_prev ? prev : a, b, a, mag, fl, np, k == AVD_FB_LEVELS - 1 && it == 0, mode)) return e;
+                    float* t = a; a = b; b = t;
+                }
             }
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            ctx->ws.flow_res[k] = a;                       // after the last swap `a` is the buffer written last
+            ctx->ws.flow_res[k] = a;                       // the buffer written last
             if (k == 0 && ctx->fb_rerun && g.flags) {
                 // pairs the level kernels flagged as ill-posed: all four levels again with the exact kernels' code (one launch; nothing
                 // to do for a pair that is not flagged), working in the levels' first flow buffers, result and |flow| where the
                 // statistics read them
-                float* fl[4] = {a, g.flow[1], g.flow[2], g.flow[3]};
+                float* fl4[4] = {a, g.flow[1], g.flow[2], g.flow[3]};
                 const float* Rk[4] = {g.poly[0], g.poly[1], g.poly[2], g.poly[3]};
                 kmark(ctx, AVD_K_RERUN);
-                if (int e = launch_fb_rerun(ctx, stream, Rk, fl, ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX, g.flags, np)) return e;
+                if (int e = launch_fb_rerun(ctx, stream, Rk, fl4, ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX, g.flags, np)) return e;
             }
             continue;
         }

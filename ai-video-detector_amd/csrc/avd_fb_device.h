@@ -124,6 +124,39 @@ __device__ __forceinline__ void ne_finish(const NeIn& in, const NeG& g, int x, i
     M[3] = r4 * r2 + r6 * r3;
     M[4] = r6 * r2 + r5 * r3;
 }
+// cv2.resize(prev, (W, W), INTER_LINEAR) * 2 (the initial flow of a pyramid level from the coarser level's result), four consecutive
+// outputs dx = 4 q .. 4 q + 3 of row dy of one component plane: k_flow_up's arithmetic (avd_farneback.hip), shared by the kernels that fold
+// that resize into themselves.  The destination is exactly twice the source, so the source coordinate d / 2 - 0.25 is exact in float:
+// weights 0.75 / 0.25; horizontally the weights snap to the edge pixel when the source index falls outside, vertically the rows are
+// clipped and the weights kept.
+template <int W>
+__device__ __forceinline__ void flow_up_chunk(const float* __restrict__ src, int dy, int q, float (&o)[4])
+{
+    constexpr int H = W, PW = W / 2, PH = H / 2;
+    float fy = dy * 0.5f - 0.25f;
+    const int sy = floor_f(fy);
+    fy -= sy;
+    const float* r0 = src + clampi(sy, 0, PH - 1) * PW;
+    const float* r1 = src + clampi(sy + 1, 0, PH - 1) * PW;
+    const float b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = q * 4 + i;
+        float fx = dx * 0.5f - 0.25f;
+        int sx = floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        bool edge = false;                                  // dx >= xmax: value copied, no weights
+        if (sx + 1 >= PW) { edge = true; if (sx >= PW - 1) { fx = 0; sx = PW - 1; } }
+        const int x1 = sx + 1 < PW - 1 ? sx + 1 : PW - 1;
+        const float a0 = 1.f - fx, a1 = fx;
+        float d0, d1;
+        if (edge) { d0 = r0[sx] * 1.f; d1 = r1[sx] * 1.f; }
+        else { d0 = r0[sx] * a0 + r0[x1] * a1; d1 = r1[sx] * a0 + r1[x1] * a1; }
+        o[i] = (d0 * b0 + d1 * b1) * 2.f;
+    }
+}
+
 // ---- leaner forms for the fused level kernel (avd_fbfused.hip): same arithmetic, fewer instructions per row ----------
 // * the warped integer position is computed once (in the gather step) and carried to the finish step;
 // * the 5-pixel border attenuation (x < 5 ? b[x] : 1) * (x >= w-5 ? b[w-x-1] : 1) * (y < 5 ? ...) * (y >= h-5 ? ...) is split

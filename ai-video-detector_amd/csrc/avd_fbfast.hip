@@ -62,6 +62,9 @@ struct FGeo {
     static constexpr int NWAVES = WPB * NB;
     static constexpr int EPS = 4 / NPB;              // entries per normal-equation wave and step
     static constexpr int CPL = 4 / XPB;              // columns per solver lane
+    // who applies the border attenuation and forms the five products of M: the chain wave where the N waves are the pole of a step
+    // (throughput shape, 320 px), the N waves where the chain wave is (latency shape: four N waves per block, one entry each per step)
+    static constexpr bool PN = NPB == 4;
     static constexpr int NE = H + kM;                // entries of the vertical chain: image row min(e, H-1)
     static constexpr int NG = (NE + 3) / 4;          // groups of four entries
     static constexpr int T = ((NG + 2 + 3) / 4) * 4; // steps (= barriers): N on group t, C on t-1, X on t-2; the loops unroll by 4
@@ -124,6 +127,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     constexpr int H = W, plane = W * H;
     constexpr int NGS = GD + 1, NIS = 2 * NGS, U = NIS / EPS;   // gather slots, input slots, steps per loop body
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
+    const float sxn = border_factor(x, W);                 // PN: x part of the border attenuation, a per-lane constant
     auto ent = [&](int i) { return 4 * (i / EPS) + EPS * k + (i % EPS); };  // this wave's i-th entry
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
@@ -161,7 +165,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
 #endif
             if (UP) flow_of(row_of(ent(i + GD + 1)), in[(ii + GD + 1) % NIS]);   // for the gather issued with the next entry
             __builtin_amdgcn_sched_barrier(0);
-            float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies
+            float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies (PN: done here)
             if constexpr (Ge::SH != 0) {
                 // loads issued (in program order) between this entry's gather and here: the inputs of that step and the gathers + inputs
                 // of the GD steps since (4 + 4 and 4 loads per entry; UP: 2 input loads).  Eight fewer are assumed, should the
@@ -174,8 +178,16 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
                 ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
             }
             float* dst = mring + (e & 7) * Ge::M_SLOT + lane;
+            if constexpr (Ge::PN) {
+                float mm[5];
+                const int er = row_of(e);
+                ne_products(a, sxn * border_factor(er, H), mm);
 #pragma unroll
-            for (int c = 0; c < 5; c++) dst[c * 64] = a[c];
+                for (int c = 0; c < 5; c++) dst[c * 64] = mm[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; c++) dst[c * 64] = a[c];
+            }
         }
     };
     constexpr int TN = H / 4;                              // steps that bring image rows in; the rest only keep the barrier count
@@ -288,7 +300,12 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
                         float rr[5], a[5];
 #pragma unroll
                         for (int c = 0; c < 5; c++) rr[c] = src[c * 64];
-                        ne_products(rr, sx * border_factor(er, H), a);       // FarnebackUpdateMatrices' last lines, moved here from the N waves
+                        if constexpr (Ge::PN) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) a[c] = rr[c];          // the N waves left the products themselves
+                        } else {
+                            ne_products(rr, sx * border_factor(er, H), a);   // FarnebackUpdateMatrices' last lines, moved here from the N waves
+                        }
                         if (e == 0) {
 #pragma unroll
                             for (int c = 0; c < 5; c++) vs[c] = (double)(a[c] * (float)(kM + 2));
@@ -446,13 +463,32 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
     FBF_WAIT_OUT(threadIdx.x >> 6, 3, fbf_t0)
 }
 
-// UP: flow_in is the PREVIOUS level's flow ([pair][2][H/2][W/2]); the launch's input flow is that, resized x 2 and doubled
-template <typename Ge, bool UP>
-__global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* __restrict__ flow_in,
-                                                              float* __restrict__ flow_out, float* __restrict__ mag_out,
-                                                              int* __restrict__ flags, int npairs, int nstrips, int ow, int zero_first, int dbg)
+// between two phases of a launch that hand the flow over through global memory (prologue -> first iteration, iteration -> next
+// iteration) INSIDE one workgroup: its waves share the CU's write-through L1, so workgroup scope is all it takes (the stores have
+// left the wave, every wave has arrived).  Agent scope here costs a write-back of the L2 per phase on this chip (the XCDs' L2s are
+// not coherent with each other): the 80-px level took 158 instead of 79 us with it.
+__device__ __forceinline__ void phase_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// UP  (320 px): flow_in is the PREVIOUS level's flow ([pair][2][H/2][W/2]); the chain wave forms the launch's input flow from it on the
+//     fly, a few rows ahead of the normal-equation waves (LDS ring).
+// PRO (160 / 80 px): flow_in is the previous level's flow as well, but the whole workgroup resizes it in a PROLOGUE into flow_tmp (the
+//     columns its own lanes read; strips of one pair write identical values where they overlap) -- at these sizes the chain wave is the
+//     pole of a step and cannot take the resize on, while a prologue costs ~1 us and saves k_flow_up's launch.
+// IT  iterations inside the launch (levels whose pairs are ONE strip: no other workgroup reads this one's flow): the flow ping-pongs
+//     between flow_out and flow_tmp through L2, one workgroup barrier between iterations; the result is in flow_out (IT odd).
+template <typename Ge, bool UP, int IT = 1, bool PRO = false>
+__global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* flow_in, float* flow_out, float* flow_tmp,
+                                                              float* __restrict__ mag_out, int* __restrict__ flags, int npairs, int nstrips, int ow,
+                                                              int zero_first, int dbg)
 {
     constexpr int W = Ge::W, NB = Ge::NB;
+    static_assert(IT == 1 || IT == 3, "one iteration per launch, or all three");
+    static_assert(!(UP && (PRO || IT > 1)), "the chain wave's resize is the 320-px launch's");
     __shared__ __align__(16) double lds[Ge::LDS_DOUBLES + (UP ? Ge::F_FLOATS / 2 : 0)];
     double* vsring = lds;
     float* mrings = reinterpret_cast<float*>(lds + Ge::VS_DOUBLES);
@@ -483,63 +519,96 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     const int x = xu < 0 ? 0 : (xu > W - 1 ? W - 1 : xu);
     float* mring = mrings + b * 8 * Ge::M_SLOT;
     float* fring = reinterpret_cast<float*>(lds + Ge::LDS_DOUBLES) + b * 16 * Ge::F_SLOT;   // UP only
+    if (PRO) {
+        // columns any lane of this strip reads: [o0 - 7, o0 - 7 + 64 NB) clamped to the image, widened to whole chunks of four
+        constexpr int H = W, plane = W * H, pplane = (W / 2) * (H / 2);
+        const int c_lo = (o0 - kM < 0 ? 0 : o0 - kM) >> 2, c_hi = (o0 - kM + 64 * NB - 1 > W - 1 ? W - 1 : o0 - kM + 64 * NB - 1) >> 2;
+        const int nq = c_hi - c_lo + 1;
+        for (int item = threadIdx.x; item < 2 * H * nq; item += 64 * Ge::NWAVES) {
+            const int q = c_lo + item % nq, dy = (item / nq) % H, c = item / (nq * H);
+            float o[4];
+            flow_up_chunk<W>(flow_in + ((size_t)p * 2 + c) * pplane, dy, q, o);
+            *reinterpret_cast<float4*>(flow_tmp + ((size_t)p * 2 + c) * plane + dy * W + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        phase_sync();
+    }
+    const float* fin0 = PRO ? flow_tmp : flow_in;
     if (role < Ge::NPB) {
-        role_ne<Ge, UP>(R, flow_in, mring, fring, p, x, role, lane, zero_first != 0);
+#pragma unroll 1
+        for (int it = 0; it < IT; it++) {
+            if (it > 0) phase_sync();
+            role_ne<Ge, UP>(R, it == 0 ? fin0 : ((it & 1) ? flow_out : flow_tmp), mring, fring, p, x, role, lane, zero_first != 0 && it == 0);
+        }
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
-        role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane);
+#pragma unroll 1
+        for (int it = 0; it < IT; it++) {
+            if (it > 0) phase_sync();
+            role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane);
+        }
     } else {
-        role_solve<Ge, UP>(vsring, flow_out, mag_out, flags, p, b, role - Ge::NPB - 1, lane, o0, width);
+#pragma unroll 1
+        for (int it = 0; it < IT; it++) {
+            if (it > 0) phase_sync();
+            role_solve<Ge, UP>(vsring, (it & 1) ? flow_tmp : flow_out, it == IT - 1 ? mag_out : nullptr, flags, p, b, role - Ge::NPB - 1, lane, o0, width);
+        }
     }
 }
 
+// mode: 0 = one iteration flow_in -> flow_out; 1 (320 px) = the same with the chain wave's resize of the previous level's flow; 2 = one
+// iteration behind a prologue that resizes the previous level's flow into flow_tmp; 3 = all three iterations (flow_in ignored when
+// zero_first, result in flow_out); 4 = prologue + all three iterations
 template <typename Ge>
-void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* mag, int* flags, int np, int nstrips, int ow, int zero_first, int up)
+void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* ftmp, float* mag, int* flags, int np, int nstrips, int ow,
+                 int zero_first, int mode)
 {
     const int grid = 8 * ((np + 7) / 8) * nstrips;
     static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
-    // the folded resize only exists where it pays: at 320 px it costs the launch 3.5 us and saves k_flow_up's 37; the small
+    const dim3 g(grid), t(64 * Ge::NWAVES);
+    // the chain wave's resize only exists where it pays: at 320 px it costs the launch 3.5 us and saves k_flow_up's 37; the small
     // levels are latency-bound on exactly the chain wave that would do it (160 px: 45 -> 84 us per launch against 12 saved)
     if constexpr (Ge::W == 320) {
-        if (up) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, flags, np, nstrips, ow, 0, dbg); return; }
+        if (mode == 1) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, 0, dbg); return; }
     }
-    hipLaunchKernelGGL((k_fb_fast<Ge, false>), dim3(grid), dim3(64 * Ge::NWAVES), 0, stream, R, fin, fout, mag, flags, np, nstrips, ow, zero_first, dbg);
+    if constexpr (Ge::W == 160 || Ge::W == 80) {
+        if (mode == 2) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 1, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, 0, dbg); return; }
+    }
+    if constexpr (Ge::W == 80) {
+        if (mode == 4) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, 0, dbg); return; }
+    }
+    if constexpr (Ge::W == 80 || Ge::W == 40) {
+        if (mode == 3) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, zero_first, dbg); return; }
+    }
+    hipLaunchKernelGGL((k_fb_fast<Ge, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, zero_first, dbg);
 }
 
 }  // namespace
 
-// ONE blur iteration of one pyramid level for `np` pairs: flow_in -> flow_out (different buffers), R = polynomial expansions
-// of np + 1 frames ([frame][y][x][5]), flows planar [pair][2][y][x]
+// Blur iterations of one pyramid level for `np` pairs: R = polynomial expansions of np + 1 frames ([frame][y][x][5]), flows planar
+// [pair][2][y][x].  mode (see launch_fast): 0 one iteration flow_in -> flow_out (different buffers); 1 / 2 the same with flow_in = the
+// previous (coarser) level's final flow [pair][2][w/2][w/2], resized on the fly (1: 320 px, by the chain wave; 2: 160 / 80 px, in a
+// prologue, through flow_tmp); 3 / 4 all three iterations in one launch (80 / 40 px: a pair is one workgroup), result in flow_out,
+// flow_tmp as the second buffer (4: behind the prologue).
 // mag_out (320-px level, last iteration; else null): float[pair][320][320] receives |flow|
-// up: flow_in is the previous (coarser) level's final flow, [pair][2][w/2][w/2]: the kernel forms this level's initial flow
-// from it on the fly (cv2: resize x 2, INTER_LINEAR, times 2) instead of reading one a separate launch wrote
 // flags (may be null): int[np]; bit k of flags[p] is set when level k (0 = 320 px) of pair p met the ill-posedness criterion
-int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int* flags,
-                   int np, int zero_first, int up)
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* flow_tmp, float* mag_out,
+                   int* flags, int np, int zero_first, int mode)
 {
     if (np <= 0) return 0;
-    if (up && w != 320) { ctx->err = "launch_fb_fast: the folded resize of the previous flow exists at 320 px only"; return AVD_ERR_ARG; }
-    if (flow_in == flow_out) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
+    const bool ok = mode == 0 || (mode == 1 && w == 320) || (mode == 2 && (w == 160 || w == 80)) || (mode == 3 && (w == 80 || w == 40)) || (mode == 4 && w == 80);
+    if (!ok) { ctx->err = "launch_fb_fast: this mode does not exist at this level size"; return AVD_ERR_ARG; }
+    if (flow_in == flow_out || (mode >= 2 && (!flow_tmp || flow_tmp == flow_out))) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
     case 320:
         // A/B (AVD_FB_VARIANT=2): neighbour-shared gathers -- bit-identical, 40 instead of 80 gathered bytes per lane and entry, but eight
         // VMEM instructions instead of six and ~25 more VALU per entry: 164 us per launch against 142 (profiles/r04_experiments.md)
-        if (var == 2) launch_fast<FGeo<320, 3, 2, 2, 1, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);
-        else launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, mag_out, flags, np, 2, 160, zero_first, up);
+        if (var == 2) launch_fast<FGeo<320, 3, 2, 2, 1, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
+        else launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
         break;
-    case 160:
-        if (var == 1) launch_fast<FGeo<160, 2, 2, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
-        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 2, 80, zero_first, up);
-        break;
-    case 80:
-        if (var == 1) launch_fast<FGeo<80, 2, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 80, zero_first, up);
-        else launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 80, zero_first, up);
-        break;
-    case 40:
-        if (var == 1) launch_fast<FGeo<40, 1, 1, 2, 1>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 40, zero_first, up);
-        else launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, w == 320 ? mag_out : nullptr, flags, np, 1, 40, zero_first, up);
-        break;
+    case 160: launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 2, 80, zero_first, mode); break;
+    case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 80, zero_first, mode); break;
+    case 40: launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 40, zero_first, mode); break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
     }
     HIP_TRY(ctx, hipGetLastError());

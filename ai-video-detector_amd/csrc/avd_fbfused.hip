@@ -512,10 +512,11 @@ __device__ __forceinline__ void flow_up_pair(const float* __restrict__ prev, flo
     }
 }
 
-// between two stages of the re-run: this workgroup's stores are in L2, its L1 holds nothing stale
+// between two stages of the re-run: the workgroup's stores have left its waves, everyone has arrived; the level bodies
+// invalidate the L1 themselves where a flow row cached earlier would be stale (workgroup scope: one CU, one write-through L1)
 __device__ __forceinline__ void rerun_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }

@@ -179,7 +179,9 @@ struct avd_ctx {
     void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
     int cnn_tiles = 0;              // convolution tiling of the CNN extension: 0 = heuristic, 1 = 256-pixel tiles, 2 = 128 x 128 wherever possible
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
-    int fb_fold_up = 1;             // fast mode: the first launch of the 320-px level forms its initial flow from the 160-px level's (no k_flow_up<320> launch); AVD_FB_FOLD_UP=0 = A/B
+    int fb_fold_up = 5;             // fast mode, bit mask (no effect on results; AVD_FB_FOLD_UP / avd_set_option): 1 the 320-px level's first launch resizes the
+                                    // 160-px flow itself (no k_flow_up<320>), 2 the 160- / 80-px levels do so in a prologue, 4 the 80- / 40-px levels run their three
+                                    // iterations in one launch
     int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
                                     // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
     int fb_rerun = 1;               // fast mode: pairs the level kernel flags as ill-posed are re-run by the exact kernels (k_fb_rerun); 0 = A/B, tests
@@ -247,10 +249,12 @@ int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, 
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
 // zero_first: the initial flow is zero whatever the buffer holds (the coarsest level: no clearing launch)
 int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first);
-// avd_fbfast.hip: ONE blur iteration of one pyramid level, a pair spread over several workgroups (column strips), the
-// horizontal window sums formed directly in double (the vertical chain stays literal); flow_in != flow_out
-int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* mag_out, int* flags,
-                   int np, int zero_first, int up);
+// avd_fbfast.hip: blur iterations of one pyramid level, a pair spread over several workgroups (column strips), the horizontal window sums
+// formed directly in double (the vertical chain stays literal).  mode 0: one iteration flow_in -> flow_out; 1 / 2: the same with flow_in =
+// the coarser level's flow, resized on the fly (320 px: by the chain wave; 160 / 80 px: in a prologue through flow_tmp); 3 / 4: all three
+// iterations in one launch (80 / 40 px), result in flow_out, flow_tmp the second buffer (4: behind the prologue)
+int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* flow_tmp, float* mag_out,
+                   int* flags, int np, int zero_first, int mode);
 // avd_fbfused.hip: re-run of the pairs with flags[p] != 0 through all four levels with the exact kernels' code, one launch; R / flow per
 // level (0 = 320 px); flow[k] is scratch for k > 0, flow[0] receives the result ([pair][2][320][320]), mag its magnitudes
 int launch_fb_rerun(avd_ctx* ctx, hipStream_t stream, const float* const R[4], float* const flow[4], float* mag, const int* flags, int np);

@@ -163,23 +163,32 @@ def test_strip_seams_and_borders(ctxs, oracle):
     assert d[:8].max() <= FLOW_TOL and d[-8:].max() <= FLOW_TOL
 
 
-def test_folded_resize_of_the_previous_flow_is_bit_identical(oracle):
-    """At 320 px the first launch of the level forms its initial flow from the 160-px level's on the fly (cv2: resize x 2,
-    INTER_LINEAR, times 2) instead of reading what k_flow_up wrote: same arithmetic, so the final flow must not change by a
-    bit -- on smooth clips, on white noise and on the hard set (flows of hundreds of pixels, first / last columns and rows)."""
+def test_folded_launches_are_bit_identical(oracle):
+    """What the fast mode folds into its level launches (option fb_fold_up, a bit mask) never changes a bit of the flow: 1 = the
+    320-px level's first launch forms its initial flow from the 160-px level's on the fly (cv2: resize x 2, INTER_LINEAR, times 2)
+    instead of reading what k_flow_up wrote; 2 = the 160- and 80-px levels do the same in a prologue of their first launch; 4 = the
+    80- and 40-px levels run their three iterations in ONE launch (flow handed over through L2 between iterations).  On smooth
+    clips, on white noise and on the hard set (flows of hundreds of pixels, first / last columns and rows).  5 is the default: the prologue (2) is as slow as the launch it saves."""
     import avd_hip
     sets = [_smalls(oracle, synth.make_clip(5, 360, 640, seed=21, dup_every=3)), synth.random_frames(4, 320, 320, seed=5)[..., 1].copy(),
             _hard_frames()]
     with avd_hip.Context(0) as c:
         c.set_option("fb_mode", 1)
         c.set_option("fb_rerun", 0)                        # the fast kernels themselves, on every pair
+        assert c.get_option("fb_fold_up") == 5
         for frames in sets:
             c.set_option("fb_fold_up", 0)
             fm0, fv0, flow0 = c.farneback_pairs(frames, want_flow=True)
-            c.set_option("fb_fold_up", 1)
-            fm1, fv1, flow1 = c.farneback_pairs(frames, want_flow=True)
-            assert np.array_equal(flow0.view(np.uint32), flow1.view(np.uint32))
-            assert np.array_equal(fm0, fm1) and np.array_equal(fv0, fv1)
+            lvl0 = [c.debug_fetch(f"flow{k}", (len(frames) - 1, 2, 320 >> k, 320 >> k), np.float32) for k in range(4)]
+            for mask in (1, 2, 4, 6, 7):
+                c.set_option("fb_fold_up", mask)
+                fm1, fv1, flow1 = c.farneback_pairs(frames, want_flow=True)
+                assert np.array_equal(flow0.view(np.uint32), flow1.view(np.uint32)), mask
+                assert np.array_equal(fm0, fm1) and np.array_equal(fv0, fv1), mask
+                for k in range(4):                         # and the final flow of every pyramid level
+                    lv = c.debug_fetch(f"flow{k}", (len(frames) - 1, 2, 320 >> k, 320 >> k), np.float32)
+                    assert np.array_equal(lv.view(np.uint32), lvl0[k].view(np.uint32)), (mask, k)
+            c.set_option("fb_fold_up", 5)
 
 
 @pytest.mark.parametrize("n,h,w,dur", [(12, 360, 640, 6.0), (6, 720, 1280, 3.0), (5, 1080, 1920, 2.5), (3, 2160, 3840, 1.5)])
