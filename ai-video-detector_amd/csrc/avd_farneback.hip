@@ -244,9 +244,12 @@ __device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, f
 #pragma unroll
         for (int q = 1; q <= 5; q++) {
             const float r0p = r0[q], r0m = r0[-q], r1p = r1[q], r1m = r1[-q], r2p = r2[q], r2m = r2[-q];
+            // tg and the taps are float VALUES held in doubles: their product has at most 48 significant bits, i.e. it is exact in
+            // double, so cv2's "b += tg * g" (a rounded product, then a rounded sum) IS the fused multiply-add, bit for bit -- one
+            // double instruction instead of two on the pass that bounds this kernel
             const double tg = (double)(r0p + r0m);
-            b1 += tg * gd[q];
-            b4 += tg * xxgd[q];
+            b1 = __builtin_fma(tg, gd[q], b1);
+            b4 = __builtin_fma(tg, xxgd[q], b4);
             const f2 d26 = (f2{r0p, r1p} - f2{r0m, r1m}) * f2{xg[q], xg[q]};     // (r0[q] - r0[-q]) * xg[q], (r1[q] - r1[-q]) * xg[q]
             const f2 s35 = (f2{r1p, r2p} + f2{r1m, r2m}) * f2{g[q], g[q]};       // (r1[q] + r1[-q]) * g[q],  (r2[q] + r2[-q]) * g[q]
             b2 += (double)d26.x;
@@ -342,8 +345,13 @@ __global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const Fb
 #pragma unroll
     for (int q = 1; q <= 5; q++) {
         const acc_t tg = (acc_t)(r0[q] + r0[-q]);
+#if defined(AVD_POLY_ABL) && (AVD_POLY_ABL & 2)
         b1 += tg * (acc_t)g[q];
         b4 += tg * (acc_t)xxg[q];
+#else
+        b1 = __builtin_fma(tg, (double)g[q], b1);          // exact products (two float values): the fma IS cv2's multiply, then add
+        b4 = __builtin_fma(tg, (double)xxg[q], b4);
+#endif
         b2 += (acc_t)((r0[q] - r0[-q]) * xg[q]);
         b3 += (acc_t)((r1[q] + r1[-q]) * g[q]);
         b6 += (acc_t)((r1[q] - r1[-q]) * xg[q]);
