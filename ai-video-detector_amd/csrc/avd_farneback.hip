@@ -1096,10 +1096,12 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         const bool fold_chain = fast && k == 0 && (ctx->fb_fold_up & 1);
         const bool fold_pro = fast && (k == 1 || k == 2) && (ctx->fb_fold_up & 2);
         const bool one_launch = fast && (k == 2 || k == 3) && (ctx->fb_fold_up & 4);
+        // bit 3: the 160- / 80- / 40-px levels run their three iterations PIPELINED in one launch (avd_fbpipe.hip); overrides bits 1 and 2
+        const bool pipe = fast && k >= 1 && (ctx->fb_fold_up & 8);
         if (k == AVD_FB_LEVELS - 1) {
             // the coarsest level starts from zero flow: the fused kernel is told so, the two-kernel path reads a cleared buffer
             if (!fast && !((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
-        } else if (fold_chain || fold_pro) {
+        } else if (fold_chain || (fold_pro && !pipe)) {
             // the level's first launch forms its initial flow from the previous level's (avd_fbfast.hip)
         } else {
             const int items = np * 2 * h * (w / 4);
@@ -1117,9 +1119,12 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             float* b = ctx->ws.d_flow2[k] + (size_t)pair_off * 2 * plane;
             int* fl = ctx->fb_rerun ? g.flags : nullptr;
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            const bool prev_in = fold_chain || fold_pro;                     // the first launch reads the previous level's flow
+            const bool prev_in = fold_chain || (fold_pro && !pipe);          // the first launch reads the previous level's flow
             const float* prev = prev_in ? ctx->ws.flow_res[k + 1] : nullptr;
-            if (one_launch) {
+            if (pipe) {
+                if (int e = launch_fb_pipe(ctx, stream, w, g.poly[k], a, b, fl, np, k == AVD_FB_LEVELS - 1)) return e;
+                a = b;
+            } else if (one_launch) {
                 // all three iterations in one launch: (prologue: prev -> a,) a -> b -> a -> b
                 if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], prev_in ? prev : a, b, a, nullptr, fl, np, k == AVD_FB_LEVELS - 1, prev_in ? 4 : 3)) return e;
                 a = b;

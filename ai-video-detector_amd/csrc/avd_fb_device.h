@@ -317,4 +317,30 @@ __device__ __forceinline__ void ne_products(const float (&r)[5], float scale, fl
     M[4] = r6 * r2 + r5 * r3;
 }
 
+// ---- shared by the fast level kernels (avd_fbfast.hip, avd_fbpipe.hip) ----------------------------------------------
+// thresholds of the ill-posedness criterion (see role_solve in avd_fbfast.hip)
+constexpr double kCondMax = 2000.;
+constexpr float kFlowMax = 0.3f;
+
+
+// 1 / d as the compiler's IEEE division sequence computes it (v_rcp_f64, two Newton steps, a correction of the quotient)
+// minus its scaling and fix-up instructions: they only act on denormal / huge / special operands, and d is a determinant
+// plus 1e-3 in [1e-3, ~1e13].  Same result as 1. / d, bit for bit, on that range (tests/test_gpu_fbfast.py compares the
+// flow of the exact kernels, which divide, against this one).
+__device__ __forceinline__ double recip_exact(double d)
+{
+#ifdef AVD_FBF_PLAIN_DIV
+    return 1. / d;
+#else
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e0 = __builtin_fma(-d, r0, 1.);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-d, r1, 1.);
+    const double r2 = __builtin_fma(r1, e1, r1);
+    const double q = 1. * r2;
+    const double e2 = __builtin_fma(-d, q, 1.);
+    return __builtin_fma(e2, r2, q);
+#endif
+}
+
 }  // namespace

@@ -334,26 +334,6 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
     FBF_WAIT_OUT(threadIdx.x >> 6, 2, fbf_t0)
 }
 
-// 1 / d as the compiler's IEEE division sequence computes it (v_rcp_f64, two Newton steps, a correction of the quotient)
-// minus its scaling and fix-up instructions: they only act on denormal / huge / special operands, and d is a determinant
-// plus 1e-3 in [1e-3, ~1e13].  Same result as 1. / d, bit for bit, on that range (tests/test_gpu_fbfast.py compares the
-// flow of the exact kernels, which divide, against this one).
-__device__ __forceinline__ double recip_exact(double d)
-{
-#ifdef AVD_FBF_PLAIN_DIV
-    return 1. / d;
-#else
-    const double r0 = __builtin_amdgcn_rcp(d);
-    const double e0 = __builtin_fma(-d, r0, 1.);
-    const double r1 = __builtin_fma(r0, e0, r0);
-    const double e1 = __builtin_fma(-d, r1, 1.);
-    const double r2 = __builtin_fma(r1, e1, r1);
-    const double q = 1. * r2;
-    const double e2 = __builtin_fma(-d, q, 1.);
-    return __builtin_fma(e2, r2, q);
-#endif
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // X: window sums of 15 columns, 2 x 2 solve (double, cv2's operation order), flow stores.  Lane = (row r of the group,
 // chunk of four output columns).  The strip's lane column u holds image column clamp(xlo + u) with xlo = o0 - 7, and vsum
@@ -370,9 +350,6 @@ __device__ __forceinline__ double recip_exact(double d)
 //   max(|fx|, |fy|) > kFlowMax * W                           a displacement beyond what a 15-px window can estimate at this
 //                                                            level (the same experiment: <= 0.25 W on well-posed pairs)
 // written so that a NaN or a negative determinant also fires.
-constexpr double kCondMax = 2000.;
-constexpr float kFlowMax = 0.3f;
-
 template <typename Ge, bool UP>
 __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, float* __restrict__ mag_out,
                                            int* __restrict__ flags, int p, int b, int xi, int lane, int o0, int ow)

@@ -181,7 +181,8 @@ struct avd_ctx {
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
     int fb_fold_up = 5;             // fast mode, bit mask (no effect on results; AVD_FB_FOLD_UP / avd_set_option): 1 the 320-px level's first launch resizes the
                                     // 160-px flow itself (no k_flow_up<320>), 2 the 160- / 80-px levels do so in a prologue, 4 the 80- / 40-px levels run their three
-                                    // iterations in one launch
+                                    // iterations in one launch, 8 (overrides 2 and 4) the 160- / 80- / 40-px levels run their three iterations PIPELINED in one launch
+                                    // (avd_fbpipe.hip; bit-identical on well-posed content, measured no faster: off by default)
     int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
                                     // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
     int fb_rerun = 1;               // fast mode: pairs the level kernel flags as ill-posed are re-run by the exact kernels (k_fb_rerun); 0 = A/B, tests
@@ -255,6 +256,9 @@ int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, flo
 // iterations in one launch (80 / 40 px), result in flow_out, flow_tmp the second buffer (4: behind the prologue)
 int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* flow_tmp, float* mag_out,
                    int* flags, int np, int zero_first, int mode);
+// avd_fbpipe.hip: all three blur iterations of a small level (w = 160 / 80 / 40) pipelined in one launch; flow_in = the level's initial flow
+// (ignored when zero_first), flow_out != flow_in receives the final one; bit-identical to the one-iteration launches of avd_fbfast.hip
+int launch_fb_pipe(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int* flags, int np, int zero_first);
 // avd_fbfused.hip: re-run of the pairs with flags[p] != 0 through all four levels with the exact kernels' code, one launch; R / flow per
 // level (0 = 320 px); flow[k] is scratch for k > 0, flow[0] receives the result ([pair][2][320][320]), mag its magnitudes
 int launch_fb_rerun(avd_ctx* ctx, hipStream_t stream, const float* const R[4], float* const flow[4], float* mag, const int* flags, int np);
