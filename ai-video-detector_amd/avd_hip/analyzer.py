@@ -6,6 +6,8 @@ reference does per sampled frame between ``cap.retrieve()`` and ``timeline_ai.ap
 """
 from __future__ import annotations
 
+import logging
+
 import collections
 import contextlib
 import os
@@ -76,12 +78,21 @@ class ContextPool:
         for c in trim:                                     # outside the lock: this synchronises the context's stream
             try:
                 c.release_workspace()
-            except Exception:                              # must not mask the request's own result (or exception)
-                pass
-            finally:
+            except Exception as exc:                       # must not mask the request's own result (or exception) ...
+                # ... but a context whose stream reports an error (sticky after a fault) must not be handed to the next request: it is
+                # logged, closed and its slot given back, so the pool creates a fresh one instead
+                logging.getLogger("avd_hip").warning("context dropped from the pool: release_workspace failed: %r", exc)
+                try:
+                    c.close()
+                except Exception:
+                    pass
                 with self._cv:
-                    self._cold.setdefault(device, []).append(c)
+                    self._count[device] = max(0, self._count.get(device, 0) - 1)
                     self._cv.notify()
+                continue
+            with self._cv:
+                self._cold.setdefault(device, []).append(c)
+                self._cv.notify()
 
     def stats(self, device: int = 0):
         with self._cv:

@@ -211,3 +211,28 @@ def test_context_pool_survives_a_failing_constructor(monkeypatch):
             with pool.borrow(0):
                 pass
     assert pool.stats(0)["created"] == 0
+
+
+def test_context_pool_drops_a_context_whose_release_fails(monkeypatch, caplog):
+    """A context whose stream reports an error when its scratch is released (a sticky HIP error after a fault) is logged, closed and
+    NOT handed to a later request; its slot is free again, so the pool creates a fresh context."""
+    from avd_hip import analyzer
+
+    class Sick(_FakeCtx):
+        def release_workspace(self):
+            raise analyzer._lib.AvdError("hipStreamSynchronize: an illegal memory access was encountered")
+
+    monkeypatch.setattr(analyzer._lib, "Context", Sick)
+    Sick.made = 0
+    pool = analyzer.ContextPool(max_contexts=2, keep_warm=1)
+    with caplog.at_level("WARNING", logger="avd_hip"):
+        with pool.borrow(0) as a:
+            with pool.borrow(0) as b:
+                pass
+    # two contexts came back, one stays warm, the other's release failed: closed, gone from the pool, slot returned
+    st = pool.stats(0)
+    assert st == {"created": 1, "warm": 1, "cold": 0}
+    assert sum(c.closed for c in (a, b)) == 1 and "release_workspace failed" in caplog.text
+    with pool.borrow(0) as c1, pool.borrow(0) as c2:                       # a fresh one can be created again
+        assert not c1.closed and not c2.closed
+    pool.close()

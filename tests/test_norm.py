@@ -72,3 +72,23 @@ def test_classifier_stack_end_to_end(ctx):
     prob, _ = ctx.softmax(logits)
     np.testing.assert_allclose(prob, torch.softmax(torch.from_numpy(logits), dim=1).numpy(), rtol=2e-6, atol=1e-9)
     assert prob.shape == (2, 1000) and np.all(prob.argmax(axis=1) == logits.argmax(axis=1))
+
+
+@pytest.mark.parametrize("rows,cols", [(3, 4), (2, 1000), (1, 1000), (7, 33), (1, 1)])
+def test_host_softmax_on_a_fresh_context(rows, cols):
+    """host operands are staged through a device buffer whose size must come from the SAME expressions as its
+    layout (gamma | beta | pad to 64 floats | x rounded up to 256 bytes | y).  Round 3 reserved 2 * bytes + 8 * cols + 256 B, less than
+    pad + round-up need for these shapes (176 / 128 / 32 bytes short); it only passed because an earlier ViT call had grown the
+    buffer.  Here every shape gets a FRESH context (nothing grown before), twice, and a larger call in between."""
+    import avd_hip
+    rng = np.random.default_rng(rows * 1000 + cols)
+    x = (rng.standard_normal((rows, cols)) * 4).astype(np.float32)
+    want = torch.softmax(torch.from_numpy(x), dim=1).numpy()
+    with avd_hip.Context(0) as c:
+        got, _ = c.softmax(x)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
+        big = (rng.standard_normal((64, 512)) * 2).astype(np.float32)
+        gb, _ = c.softmax(big)
+        np.testing.assert_allclose(gb, torch.softmax(torch.from_numpy(big), dim=1).numpy(), rtol=2e-6, atol=1e-9)
+        got2, _ = c.softmax(x)
+        assert np.array_equal(got, got2)

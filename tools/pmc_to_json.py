@@ -42,6 +42,18 @@ for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_fb_fast<320>", r"
         nl = sum(k["launches"] for _, k in hit)
         res[short] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for _, k in hit) / nl, "kernel": " + ".join(n for n, _ in hit),
                       "launches": nl}
+        # fractions of the launch the vector ALUs / the texture addresser were busy: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
+        # chip's 1024 SIMDs, TA_BUSY_avr cycles averaged over the TA instances, GRBM_GUI_ACTIVE the cycles of the launch
+        def wmean(c):
+            v = [(k[c], k["launches"]) for _, k in hit if c in k]
+            return sum(a * b for a, b in v) / sum(b for _, b in v) if v else None
+        act, valu, ta = wmean("GRBM_GUI_ACTIVE"), wmean("SQ_ACTIVE_INST_VALU"), wmean("TA_BUSY_avr")
+        if act:
+            res[short]["gui_active_cycles"] = act
+            if valu is not None:
+                res[short]["valu_issue_frac"] = round(valu * 4 / 1024 / act, 4)
+            if ta is not None:
+                res[short]["ta_busy_frac"] = round(ta / act, 4)
 fb = [k for n, k in kernels.items() if re.search(r"k_fb_level|k_fb_fast|k_pyramid|k_polyexp|k_flow_up|k_stats|k_uv|k_hscan", n) and "hbm_bytes" in k]
 if fb:
     # per clip: launches per clip = launches / clips in the trace; every kernel above is launched a fixed number of times per clip
