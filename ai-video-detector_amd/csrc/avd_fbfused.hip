@@ -524,10 +524,14 @@ __device__ __forceinline__ void rerun_sync()
 __global__ __launch_bounds__(512) void k_fb_rerun(RerunArgs a)
 {
     __shared__ __align__(16) double lds[Geo<320, 4, 2>::LDS_DOUBLES];
-    const int p = blockIdx.x;
-    if (p >= a.npairs || a.flags[p] == 0) return;         // whole workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int dbg = 0;
+    // a workgroup needs a whole CU (160 KB of LDS, 512 threads at 256 registers): the grid is SMALL (kRerunGrid workgroups, each
+    // taking pairs blockIdx.x, + gridDim.x, ...) so that the usual case -- nothing flagged -- does not make 119 workgroups wait for
+    // 119 CUs to drain while other clips' kernels run (three clips in flight: 19 us per clip with one workgroup per pair)
+    for (int p = blockIdx.x; p < a.npairs; p += gridDim.x) {
+    if (a.flags[p] == 0) continue;                        // whole workgroup
+    rerun_sync();                                         // (a previous pair of this workgroup: LDS is reused)
     float* f3 = a.flow[3] + (size_t)p * 2 * 40 * 40;
     float* f2 = a.flow[2] + (size_t)p * 2 * 80 * 80;
     float* f1 = a.flow[1] + (size_t)p * 2 * 160 * 160;
@@ -557,6 +561,7 @@ __global__ __launch_bounds__(512) void k_fb_rerun(RerunArgs a)
         m.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
         reinterpret_cast<flt4*>(mg)[i] = m;
     }
+    }
 }
 
 }  // namespace
@@ -569,7 +574,8 @@ int launch_fb_rerun(avd_ctx* ctx, hipStream_t stream, const float* const R[4], f
     RerunArgs a;
     for (int k = 0; k < 4; k++) { a.R[k] = R[k]; a.flow[k] = flow[k]; }
     a.mag = mag; a.flags = flags; a.npairs = np;
-    hipLaunchKernelGGL(k_fb_rerun, dim3(np), dim3(512), 0, stream, a);
+    constexpr int kRerunGrid = 32;
+    hipLaunchKernelGGL(k_fb_rerun, dim3(np < kRerunGrid ? np : kRerunGrid), dim3(512), 0, stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
