@@ -848,8 +848,10 @@ def main():
         dominant["valu_issue_frac_from_profiles"] = pmc_k.get("valu_issue_frac")
         dominant["ta_busy_frac_from_profiles"] = pmc_k.get("ta_busy_frac")
         dominant["frac_of_vector_peak"] = (dominant.get("valu") or {}).get("frac_of_vector_peak")
-        dominant["preprocess_frac"] = pre["frac"]
         dominant["kernels"] = kernel_table(n, h, w, kms, None if nv12 is None else nv12["pre_ms"])
+        # north_star's ">= 60 % of the HBM peak on preprocessing": the fused kernel alone (its row of the table), not the stage that also
+        # holds the aHash kernel and the profiling events
+        dominant["preprocess_frac"] = next((k["frac"] for k in dominant["kernels"] if k["name"] == "preprocess"), pre["frac"])
         out = {
             "metric": "sampled frames/sec analysed (1080p30 60 s clip, 2 fps sampling)",
             "value": round(fps(elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

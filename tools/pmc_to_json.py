@@ -43,12 +43,14 @@ for short, pat in (("k_fb_level<320>", r"k_fb_level<320"), ("k_fb_fast<320>", r"
         res[short] = {"hbm_bytes": sum(k["hbm_bytes"] * k["launches"] for _, k in hit) / nl, "kernel": " + ".join(n for n, _ in hit),
                       "launches": nl}
         # fractions of the launch the vector ALUs / the texture addresser were busy: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
-        # chip's 1024 SIMDs, TA_BUSY_avr cycles averaged over the TA instances, GRBM_GUI_ACTIVE the cycles of the launch
+        # chip's 1024 SIMDs, TA_BUSY_avr cycles averaged over the TA instances, GRBM_GUI_ACTIVE the cycles of the launch SUMMED over the
+        # chip's 8 XCDs (each has its own GRBM: 2.66 M for a 141-us launch = 8 x 333 k cycles at ~2.36 GHz)
         def wmean(c):
             v = [(k[c], k["launches"]) for _, k in hit if c in k]
             return sum(a * b for a, b in v) / sum(b for _, b in v) if v else None
         act, valu, ta = wmean("GRBM_GUI_ACTIVE"), wmean("SQ_ACTIVE_INST_VALU"), wmean("TA_BUSY_avr")
         if act:
+            act /= 8.0
             res[short]["gui_active_cycles"] = act
             if valu is not None:
                 res[short]["valu_issue_frac"] = round(valu * 4 / 1024 / act, 4)
