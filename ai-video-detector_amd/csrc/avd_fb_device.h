@@ -34,6 +34,15 @@ __device__ __forceinline__ T ld_off(const void* __restrict__ base, unsigned byte
     return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
 }
 
+// A further piece of the same pixel: the constant is added AFTER the 32-bit offset has been widened, which is the form the compiler folds
+// into the load's immediate offset field ("+ 16" on the 32-bit offset could wrap, so it would need a v_add_u32 per piece: 42 of the 585
+// VALU instructions of the N waves' loop)
+template <typename T, unsigned IMM>
+__device__ __forceinline__ T ld_off_i(const void* __restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + (size_t)byte_off + IMM);
+}
+
 template <typename T>
 __device__ __forceinline__ void st_off(void* __restrict__ base, unsigned byte_off, T v)
 {
@@ -57,7 +66,7 @@ __device__ __forceinline__ void ne_load(const float* __restrict__ R, const float
     in.dx = ld_off<float>(flow, (flbase + o) * 4u); in.dy = ld_off<float>(flow, (flbase + plane + o) * 4u);
     const unsigned pb = (r0base + o * 5u) * 4u;
     const F4 v = ld_off<F4>(R, pb);
-    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off<float>(R, pb + 16u);
+    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off_i<float, 16>(R, pb);
 }
 
 // the R0 part alone (the flow comes from elsewhere)
@@ -65,7 +74,7 @@ __device__ __forceinline__ void ne_load_r0(const float* __restrict__ R, unsigned
 {
     const unsigned pb = (r0base + (unsigned)(y * w + x) * 5u) * 4u;
     const F4 v = ld_off<F4>(R, pb);
-    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off<float>(R, pb + 16u);
+    in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off_i<float, 16>(R, pb);
 }
 
 // gather the four bilinear neighbours of the warped position (clamped address when outside:
@@ -76,10 +85,10 @@ __device__ __forceinline__ void ne_gather(const float* __restrict__ R, unsigned 
     const float fx = x + in.dx, fy = y + in.dy;
     const int x1 = clampi(floor_f(fx), 0, w - 2), y1 = clampi(floor_f(fy), 0, h - 2);
     const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
-    const F4 t0 = ld_off<F4>(R, pb), t1 = ld_off<F4>(R, pb + 16u);
-    const F2 t2 = ld_off<F2>(R, pb + 32u);
-    const F4 b0 = ld_off<F4>(R, qb), b1 = ld_off<F4>(R, qb + 16u);
-    const F2 b2 = ld_off<F2>(R, qb + 32u);
+    const F4 t0 = ld_off<F4>(R, pb), t1 = ld_off_i<F4, 16>(R, pb);
+    const F2 t2 = ld_off_i<F2, 32>(R, pb);
+    const F4 b0 = ld_off<F4>(R, qb), b1 = ld_off_i<F4, 16>(R, qb);
+    const F2 b2 = ld_off_i<F2, 32>(R, qb);
     g.top[0] = t0.a; g.top[1] = t0.b; g.top[2] = t0.c; g.top[3] = t0.d; g.top[4] = t1.a;
     g.top[5] = t1.b; g.top[6] = t1.c; g.top[7] = t1.d; g.top[8] = t2.a; g.top[9] = t2.b;
     g.bot[0] = b0.a; g.bot[1] = b0.b; g.bot[2] = b0.c; g.bot[3] = b0.d; g.bot[4] = b1.a;
@@ -163,7 +172,27 @@ __device__ __forceinline__ void flow_up_chunk(const float* __restrict__ src, int
 //   into a per-lane factor sx (constant for the whole kernel) and a per-row factor sy (wave-uniform).  For images of at
 //   least 10 pixels at most one x factor and one y factor differ from 1, so cv2's left-to-right product equals sx * sy
 //   bit for bit (multiplications by 1.0f are exact), and interior pixels multiply by exactly 1.
-struct NeG2 { float top[10], bot[10]; int x1, y1; };
+typedef float fv2 __attribute__((ext_vector_type(2)));
+typedef float fv4 __attribute__((ext_vector_type(4)));
+// the gathered rows as the three loads of a row deliver them: t0 = px0 c0..c3, t1 = (px0 c4, px1 c0, px1 c1, px1 c2), t2 = (px1 c3, px1 c4)
+struct NeG2 { fv4 t0, t1; fv2 t2; fv4 b0, b1; fv2 b2; int x1, y1; };
+
+// The bilinear sample of the five coefficients, cv2's operation order per channel -- ((a00 p00 + a01 p01) + a10 p10) + a11 p11 -- with the
+// TEN products of a row formed as five packed multiplies on the register pairs the loads delivered (px1's coefficients start at an odd
+// register: pairing by channel across the two pixels, or by pixel across channels, both need a move per pair -- 116 of the 585 VALU
+// instructions of the N waves' loop were v_mov); the sums are scalar adds, which read any register.  Same IEEE operations: bit-identical.
+__device__ __forceinline__ void ne_bilinear(const NeG2& g, float a00, float a01, float a10, float a11, float (&b)[5])
+{
+    const fv2 w00 = {a00, a00}, w0x = {a00, a01}, w01 = {a01, a01};
+    const fv2 w10 = {a10, a10}, w1x = {a10, a11}, w11 = {a11, a11};
+    const fv2 PA = g.t0.xy * w00, PB = g.t0.zw * w00, PC = g.t1.xy * w0x, PD = g.t1.zw * w01, PE = g.t2 * w01;
+    const fv2 QA = g.b0.xy * w10, QB = g.b0.zw * w10, QC = g.b1.xy * w1x, QD = g.b1.zw * w11, QE = g.b2 * w11;
+    b[0] = ((PA.x + PC.y) + QA.x) + QC.y;
+    b[1] = ((PA.y + PD.x) + QA.y) + QD.x;
+    b[2] = ((PB.x + PD.y) + QB.x) + QD.y;
+    b[3] = ((PB.y + PE.x) + QB.y) + QE.x;
+    b[4] = ((PC.x + PE.y) + QC.x) + QE.y;
+}
 
 __device__ __forceinline__ float border_factor(int p, int len)
 {
@@ -180,14 +209,10 @@ __device__ __forceinline__ void ne_gather2(const float* __restrict__ R, unsigned
     g.x1 = floor_f(fx); g.y1 = floor_f(fy);
     const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
     const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
-    const F4 t0 = ld_off<F4>(R, pb), t1 = ld_off<F4>(R, pb + 16u);
-    const F2 t2 = ld_off<F2>(R, pb + 32u);
-    const F4 b0 = ld_off<F4>(R, qb), b1 = ld_off<F4>(R, qb + 16u);
-    const F2 b2 = ld_off<F2>(R, qb + 32u);
-    g.top[0] = t0.a; g.top[1] = t0.b; g.top[2] = t0.c; g.top[3] = t0.d; g.top[4] = t1.a;
-    g.top[5] = t1.b; g.top[6] = t1.c; g.top[7] = t1.d; g.top[8] = t2.a; g.top[9] = t2.b;
-    g.bot[0] = b0.a; g.bot[1] = b0.b; g.bot[2] = b0.c; g.bot[3] = b0.d; g.bot[4] = b1.a;
-    g.bot[5] = b1.b; g.bot[6] = b1.c; g.bot[7] = b1.d; g.bot[8] = b2.a; g.bot[9] = b2.b;
+    g.t0 = __builtin_bit_cast(fv4, ld_off<F4>(R, pb)); g.t1 = __builtin_bit_cast(fv4, ld_off_i<F4, 16>(R, pb));
+    g.t2 = __builtin_bit_cast(fv2, ld_off_i<F2, 32>(R, pb));
+    g.b0 = __builtin_bit_cast(fv4, ld_off<F4>(R, qb)); g.b1 = __builtin_bit_cast(fv4, ld_off_i<F4, 16>(R, qb));
+    g.b2 = __builtin_bit_cast(fv2, ld_off_i<F2, 32>(R, qb));
 }
 
 __device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x, int y, int w, int h, float sx, float sy,
@@ -198,11 +223,9 @@ __device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x,
     const float fx = (x + dx) - x1, fy = (y + dy) - y1;
     const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    const float b2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
-    const float b3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
-    const float b4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
-    const float b5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
-    const float b6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
+    float bb[5];
+    ne_bilinear(g, a00, a01, a10, a11, bb);
+    const float b2 = bb[0], b3 = bb[1], b4 = bb[2], b5 = bb[3], b6 = bb[4];
     float r2 = inside ? b2 : 0.f, r3 = inside ? b3 : 0.f;
     float r4 = inside ? (in.r0[2] + b4) * 0.5f : in.r0[2];
     float r5 = inside ? (in.r0[3] + b5) * 0.5f : in.r0[3];
@@ -230,11 +253,9 @@ __device__ __forceinline__ void ne_finish_r(const NeIn& in, const NeG2& g, int x
     const float fx = (x + dx) - x1, fy = (y + dy) - y1;
     const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    const float b2 = a00 * g.top[0] + a01 * g.top[5] + a10 * g.bot[0] + a11 * g.bot[5];
-    const float b3 = a00 * g.top[1] + a01 * g.top[6] + a10 * g.bot[1] + a11 * g.bot[6];
-    const float b4 = a00 * g.top[2] + a01 * g.top[7] + a10 * g.bot[2] + a11 * g.bot[7];
-    const float b5 = a00 * g.top[3] + a01 * g.top[8] + a10 * g.bot[3] + a11 * g.bot[8];
-    const float b6 = a00 * g.top[4] + a01 * g.top[9] + a10 * g.bot[4] + a11 * g.bot[9];
+    float bb[5];
+    ne_bilinear(g, a00, a01, a10, a11, bb);
+    const float b2 = bb[0], b3 = bb[1], b4 = bb[2], b5 = bb[3], b6 = bb[4];
     float r2 = inside ? b2 : 0.f, r3 = inside ? b3 : 0.f;
     const float r4 = inside ? (in.r0[2] + b4) * 0.5f : in.r0[2];
     const float r5 = inside ? (in.r0[3] + b5) * 0.5f : in.r0[3];
@@ -275,9 +296,9 @@ __device__ __forceinline__ void ne_gather3(const float* __restrict__ R, unsigned
     const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
     const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
     const F4 t0 = ld_off<F4>(R, pb);
-    const float t1 = ld_off<float>(R, pb + 16u);
+    const float t1 = ld_off_i<float, 16>(R, pb);
     const F4 b0 = ld_off<F4>(R, qb);
-    const float b1 = ld_off<float>(R, qb + 16u);
+    const float b1 = ld_off_i<float, 16>(R, qb);
     g.lt[0] = t0.a; g.lt[1] = t0.b; g.lt[2] = t0.c; g.lt[3] = t0.d; g.lt[4] = t1;
     g.lb[0] = b0.a; g.lb[1] = b0.b; g.lb[2] = b0.c; g.lb[3] = b0.d; g.lb[4] = b1;
     const int key = y1 * w + x1;                                            // one comparison for both coordinates (x1 <= w - 2)
@@ -300,9 +321,9 @@ __device__ __forceinline__ void ne_share3(NeG3& g, NeG2& o)
     for (int c = 0; c < 5; c++) {
         const float nt = __builtin_bit_cast(float, dpp_from_next_lane(__builtin_bit_cast(int, g.lt[c])));
         const float nb = __builtin_bit_cast(float, dpp_from_next_lane(__builtin_bit_cast(int, g.lb[c])));
-        o.top[c] = g.lt[c]; o.bot[c] = g.lb[c];
-        o.top[5 + c] = g.own ? rt[c] : nt;
-        o.bot[5 + c] = g.own ? rb[c] : nb;
+        const float tr = g.own ? rt[c] : nt, br = g.own ? rb[c] : nb;
+        if (c < 4) { o.t0[c] = g.lt[c]; o.b0[c] = g.lb[c]; } else { o.t1[0] = g.lt[4]; o.b1[0] = g.lb[4]; }
+        if (c < 3) { o.t1[1 + c] = tr; o.b1[1 + c] = br; } else { o.t2[c - 3] = tr; o.b2[c - 3] = br; }
     }
     o.x1 = g.x1; o.y1 = g.y1;
 }
