@@ -175,7 +175,8 @@ __device__ __forceinline__ void flow_up_chunk(const float* __restrict__ src, int
 typedef float fv2 __attribute__((ext_vector_type(2)));
 typedef float fv4 __attribute__((ext_vector_type(4)));
 // the gathered rows as the three loads of a row deliver them: t0 = px0 c0..c3, t1 = (px0 c4, px1 c0, px1 c1, px1 c2), t2 = (px1 c3, px1 c4)
-struct NeG2 { fv4 t0, t1; fv2 t2; fv4 b0, b1; fv2 b2; int x1, y1; };
+// fx, fy: fractional parts of the warped position; inside: cv2's test (unsigned)x1 < w - 1 && (unsigned)y1 < h - 1
+struct NeG2 { fv4 t0, t1; fv2 t2; fv4 b0, b1; fv2 b2; float fx, fy; bool inside; };
 
 // The bilinear sample of the five coefficients, cv2's operation order per channel -- ((a00 p00 + a01 p01) + a10 p10) + a11 p11 -- with the
 // TEN products of a row formed as five packed multiplies on the register pairs the loads delivered (px1's coefficients start at an odd
@@ -205,9 +206,13 @@ __device__ __forceinline__ float border_factor(int p, int len)
 __device__ __forceinline__ void ne_gather2(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
                                            int w, int h, NeG2& g, bool zf = false)
 {
+    // cvFloor and "fx -= x1" through v_floor_f32: floorf(v) IS (float)cvFloor(v) for |v| < 2^24 (and the same value beyond), three
+    // instructions per coordinate (floor, convert, subtract) instead of six (truncate, convert back, compare, borrow, convert, subtract)
     const float fx = x + (zf ? 0.f : in.dx), fy = y + (zf ? 0.f : in.dy);
-    g.x1 = floor_f(fx); g.y1 = floor_f(fy);
-    const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
+    const float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
+    g.fx = fx - flx; g.fy = fy - fly;
+    g.inside = flx >= 0.f && flx <= (float)(w - 2) && fly >= 0.f && fly <= (float)(h - 2);
+    const int x1 = clampi((int)flx, 0, w - 2), y1 = clampi((int)fly, 0, h - 2);
     const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
     g.t0 = __builtin_bit_cast(fv4, ld_off<F4>(R, pb)); g.t1 = __builtin_bit_cast(fv4, ld_off_i<F4, 16>(R, pb));
     g.t2 = __builtin_bit_cast(fv2, ld_off_i<F2, 32>(R, pb));
@@ -219,9 +224,8 @@ __device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x,
                                            float (&M)[5], bool zf = false)
 {
     const float dx = zf ? 0.f : in.dx, dy = zf ? 0.f : in.dy;
-    const int x1 = g.x1, y1 = g.y1;
-    const float fx = (x + dx) - x1, fy = (y + dy) - y1;
-    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const float fx = g.fx, fy = g.fy;
+    const bool inside = g.inside;
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     float bb[5];
     ne_bilinear(g, a00, a01, a10, a11, bb);
@@ -249,9 +253,8 @@ __device__ __forceinline__ void ne_finish2(const NeIn& in, const NeG2& g, int x,
 __device__ __forceinline__ void ne_finish_r(const NeIn& in, const NeG2& g, int x, int y, int w, int h, float (&r)[5], bool zf = false)
 {
     const float dx = zf ? 0.f : in.dx, dy = zf ? 0.f : in.dy;
-    const int x1 = g.x1, y1 = g.y1;
-    const float fx = (x + dx) - x1, fy = (y + dy) - y1;
-    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const float fx = g.fx, fy = g.fy;
+    const bool inside = g.inside;
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     float bb[5];
     ne_bilinear(g, a00, a01, a10, a11, bb);
@@ -265,67 +268,6 @@ __device__ __forceinline__ void ne_finish_r(const NeIn& in, const NeG2& g, int x
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     r[0] = r2; r[1] = r3; r[2] = r4; r[3] = r5; r[4] = r6;
-}
-
-// ---- neighbour-shared gather (round 4, fast level kernel at 320 px) ------------------------------------------------
-// The bilinear footprint of a lane is pixels x1, x1 + 1 of rows y1, y1 + 1 of R1: 4 x 20 bytes, and where the flow is smooth
-// lane l + 1's LEFT pixel is lane l's RIGHT one.  A lane therefore loads only its left pixel (both rows: 40 bytes instead
-// of 80 through the texture-addresser / L1 path, which limits this kernel) and takes the right one from lane l + 1 with a
-// DPP wave shift when that lane's clamped position is exactly (x1 + 1, y1); lanes for which it is not (the floor of x + dx
-// does not advance by one, another row, lane 63, clamped positions at the image edge) fetch their right pixel themselves
-// with loads that only they execute.  Same values from the same addresses as ne_gather2: bit-identical.
-typedef float flt4v __attribute__((ext_vector_type(4)));
-struct NeG3 { float lt[5], lb[5]; flt4v rt, rb; float rt4, rb4; int x1, y1; bool own; };   // left top / bottom; right top / bottom (own load, if `own`)
-
-__device__ __forceinline__ int dpp_from_next_lane(int v)      // lane l receives lane l + 1's value (lane 63: 0)
-{
-    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, false);      // wave_shl:1
-}
-
-// The own-lanes-only loads are BUFFER loads whose offset is out of range for every other lane (the hardware's range check
-// returns zero for those without touching memory): no divergent control flow -- as a divergent `if` the compiler merges the
-// loaded registers with the untaken path inside the block, behind an s_waitcnt for the loads just issued, and every entry
-// waits a full memory round trip (ISA: vmcnt(3) / vmcnt(2) right after the four loads) -- and no hand-counted waits.
-typedef int int4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void ne_gather3(const float* __restrict__ R, unsigned r1base, const NeIn& in, int x, int y,
-                                           int w, int h, int lane, NeG3& g, bool zf = false)
-{
-    const float fx = x + (zf ? 0.f : in.dx), fy = y + (zf ? 0.f : in.dy);
-    g.x1 = floor_f(fx); g.y1 = floor_f(fy);
-    const int x1 = clampi(g.x1, 0, w - 2), y1 = clampi(g.y1, 0, h - 2);
-    const unsigned pb = (r1base + (unsigned)(y1 * w + x1) * 5u) * 4u, qb = pb + (unsigned)w * 20u;
-    const F4 t0 = ld_off<F4>(R, pb);
-    const float t1 = ld_off_i<float, 16>(R, pb);
-    const F4 b0 = ld_off<F4>(R, qb);
-    const float b1 = ld_off_i<float, 16>(R, qb);
-    g.lt[0] = t0.a; g.lt[1] = t0.b; g.lt[2] = t0.c; g.lt[3] = t0.d; g.lt[4] = t1;
-    g.lb[0] = b0.a; g.lb[1] = b0.b; g.lb[2] = b0.c; g.lb[3] = b0.d; g.lb[4] = b1;
-    const int key = y1 * w + x1;                                            // one comparison for both coordinates (x1 <= w - 2)
-    g.own = lane == 63 || dpp_from_next_lane(key) != key + 1;
-    // every offset into R is below 2 GiB (the largest expansion buffer is ~1 GiB): 0x80000000 is out of range
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
-    const int po = g.own ? (int)(pb + 20u) : (int)0x80000000, qo = g.own ? (int)(qb + 20u) : (int)0x80000000;
-    const int4v u0 = __builtin_amdgcn_raw_buffer_load_b128(rs, po, 0, 0), v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, qo, 0, 0);
-    const int u4 = __builtin_amdgcn_raw_buffer_load_b32(rs, po + 16, 0, 0), v4 = __builtin_amdgcn_raw_buffer_load_b32(rs, qo + 16, 0, 0);
-    g.rt = __builtin_bit_cast(flt4v, u0); g.rb = __builtin_bit_cast(flt4v, v0);
-    g.rt4 = __builtin_bit_cast(float, u4); g.rb4 = __builtin_bit_cast(float, v4);
-}
-
-// the right-hand pixel: the neighbour's left one, or the lane's own load (K: see ne_gather3)
-template <int K>
-__device__ __forceinline__ void ne_share3(NeG3& g, NeG2& o)
-{
-    const float rt[5] = {g.rt.x, g.rt.y, g.rt.z, g.rt.w, g.rt4}, rb[5] = {g.rb.x, g.rb.y, g.rb.z, g.rb.w, g.rb4};
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float nt = __builtin_bit_cast(float, dpp_from_next_lane(__builtin_bit_cast(int, g.lt[c])));
-        const float nb = __builtin_bit_cast(float, dpp_from_next_lane(__builtin_bit_cast(int, g.lb[c])));
-        const float tr = g.own ? rt[c] : nt, br = g.own ? rb[c] : nb;
-        if (c < 4) { o.t0[c] = g.lt[c]; o.b0[c] = g.lb[c]; } else { o.t1[0] = g.lt[4]; o.b1[0] = g.lb[4]; }
-        if (c < 3) { o.t1[1 + c] = tr; o.b1[1 + c] = br; } else { o.t2[c - 3] = tr; o.b2[c - 3] = br; }
-    }
-    o.x1 = g.x1; o.y1 = g.y1;
 }
 
 __device__ __forceinline__ void ne_products(const float (&r)[5], float scale, float (&M)[5])

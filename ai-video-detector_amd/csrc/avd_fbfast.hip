@@ -52,10 +52,9 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 // entries each per step, 4: one each); XPB solver waves per block (1: four columns per lane, 2: two columns per lane).
 // 2 + 1 + 1 waves per block is the throughput shape (320 px: the chip is full and total issue counts); 4 + 1 + 2 is the
 // latency shape for the small levels, where a launch is steps x the slowest wave of a step and most CUs are idle anyway.
-// SH: the bilinear gather shares pixels between neighbouring lanes (ne_gather3, avd_fb_device.h)
-template <int W_, int NB_, int GD_ = 1, int NPB_ = 2, int XPB_ = 1, int SH_ = 0>
+template <int W_, int NB_, int GD_ = 1, int NPB_ = 2, int XPB_ = 1>
 struct FGeo {
-    static constexpr int W = W_, NB = NB_, GD = GD_, NPB = NPB_, XPB = XPB_, SH = SH_;
+    static constexpr int W = W_, NB = NB_, GD = GD_, NPB = NPB_, XPB = XPB_;
     static constexpr int H = W;
     static constexpr int SW = 64 * NB;               // lane columns of a strip
     static constexpr int WPB = NPB + 1 + XPB;        // waves per block
@@ -115,10 +114,12 @@ __device__ __forceinline__ void fb_barrier() { __syncthreads(); }
 // Slots are statically indexed: the loop body is GD + 1 steps = 2 (GD + 1) entries.
 // UP: the flow of this launch is the previous level's, resized: the chain wave leaves row y of it in fring[y & 15] at least
 // one step before it is wanted here (see role_chain); it is fetched from there one entry before the gather that needs it.
-template <typename Ge, bool UP>
+// ZF (compile time: only the coarsest level's first iteration has it): the flow is known to be zero whatever the buffer holds
+template <typename Ge, bool UP, bool ZF = false>
 __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
-                                        const float* __restrict__ fring, int p, int x, int k, int lane, bool zf)
+                                        const float* __restrict__ fring, int p, int x, int k, int lane)
 {
+    constexpr bool zf = ZF;
     constexpr int W = Ge::W, GD = Ge::GD, EPS = Ge::EPS;
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
@@ -131,11 +132,8 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     auto ent = [&](int i) { return 4 * (i / EPS) + EPS * k + (i % EPS); };  // this wave's i-th entry
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
-    typename std::conditional<Ge::SH != 0, NeG3, NeG2>::type g[NGS];
-    auto gather = [&](const NeIn& s, int row, auto& gs) __attribute__((always_inline)) {
-        if constexpr (Ge::SH != 0) ne_gather3(R, r1base, s, x, row, W, H, lane, gs, zf);
-        else ne_gather2(R, r1base, s, x, row, W, H, gs, zf);
-    };
+    NeG2 g[NGS];
+    auto gather = [&](const NeIn& s, int row, NeG2& gs) __attribute__((always_inline)) { ne_gather2(R, r1base, s, x, row, W, H, gs, zf); };
     auto flow_of = [&](int row, NeIn& s) { const float* f = fring + (row & 15) * Ge::F_SLOT + lane; s.dx = f[0]; s.dy = f[64]; };
     auto load_in = [&](int row, NeIn& s) {
         if (UP) ne_load_r0(R, r0base, x, row, W, s);
@@ -166,17 +164,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
             if (UP) flow_of(row_of(ent(i + GD + 1)), in[(ii + GD + 1) % NIS]);   // for the gather issued with the next entry
             __builtin_amdgcn_sched_barrier(0);
             float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies (PN: done here)
-            if constexpr (Ge::SH != 0) {
-                // loads issued (in program order) between this entry's gather and here: the inputs of that step and the gathers + inputs
-                // of the GD steps since (4 + 4 and 4 loads per entry; UP: 2 input loads).  Eight fewer are assumed, should the
-                // compiler have moved some of its loads across the assembly block
-                constexpr int KW = (UP ? 2 : 4) + GD * (8 + (UP ? 2 : 4)) - 8;
-                NeG2 full;
-                ne_share3<KW>(g[ii % NGS], full);
-                ne_finish_r(in[ii % NIS], full, x, e, W, H, a, zf);
-            } else {
-                ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
-            }
+            ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
             float* dst = mring + (e & 7) * Ge::M_SLOT + lane;
             if constexpr (Ge::PN) {
                 float mm[5];
@@ -514,7 +502,9 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
 #pragma unroll 1
         for (int it = 0; it < IT; it++) {
             if (it > 0) phase_sync();
-            role_ne<Ge, UP>(R, it == 0 ? fin0 : ((it & 1) ? flow_out : flow_tmp), mring, fring, p, x, role, lane, zero_first != 0 && it == 0);
+            const float* fin = it == 0 ? fin0 : ((it & 1) ? flow_out : flow_tmp);
+            if (Ge::W == 40 && zero_first != 0 && it == 0) role_ne<Ge, UP, Ge::W == 40>(R, fin, mring, fring, p, x, role, lane);
+            else role_ne<Ge, UP, false>(R, fin, mring, fring, p, x, role, lane);
         }
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
@@ -575,13 +565,11 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
     const bool ok = mode == 0 || (mode == 1 && w == 320) || (mode == 2 && (w == 160 || w == 80)) || (mode == 3 && (w == 80 || w == 40)) || (mode == 4 && w == 80);
     if (!ok) { ctx->err = "launch_fb_fast: this mode does not exist at this level size"; return AVD_ERR_ARG; }
     if (flow_in == flow_out || (mode >= 2 && (!flow_tmp || flow_tmp == flow_out))) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
-    static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B knob
     switch (w) {
     case 320:
-        // A/B (AVD_FB_VARIANT=2): neighbour-shared gathers -- bit-identical, 40 instead of 80 gathered bytes per lane and entry, but eight
-        // VMEM instructions instead of six and ~25 more VALU per entry: 164 us per launch against 142 (profiles/r04_experiments.md)
-        if (var == 2) launch_fast<FGeo<320, 3, 2, 2, 1, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
-        else launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
+        // (neighbour-shared gathers -- each lane loads its left pixel, the right one comes from lane + 1 by a DPP wave shift -- were built,
+        // bit-identical and slower, 164 us per launch against 142: profiles/r04_experiments.md section 2; the code is in the history, commit 3e8b43a)
+        launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
         break;
     case 160: launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 2, 80, zero_first, mode); break;
     case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 80, zero_first, mode); break;
