@@ -243,6 +243,8 @@ __device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, f
 #else
 #pragma unroll
         for (int q = 1; q <= 5; q++) {
+            // scalar float operations on purpose: formed as two-component vectors ((r0, r1) differences, (r1, r2) sums) every pair had to
+            // be assembled with register moves first -- 40 of the 208 VALU instructions of a row -- which cost more than the packing saved
             const float r0p = r0[q], r0m = r0[-q], r1p = r1[q], r1m = r1[-q], r2p = r2[q], r2m = r2[-q];
             // tg and the taps are float VALUES held in doubles: their product has at most 48 significant bits, i.e. it is exact in
             // double, so cv2's "b += tg * g" (a rounded product, then a rounded sum) IS the fused multiply-add, bit for bit -- one
@@ -250,12 +252,10 @@ __device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, f
             const double tg = (double)(r0p + r0m);
             b1 = __builtin_fma(tg, gd[q], b1);
             b4 = __builtin_fma(tg, xxgd[q], b4);
-            const f2 d26 = (f2{r0p, r1p} - f2{r0m, r1m}) * f2{xg[q], xg[q]};     // (r0[q] - r0[-q]) * xg[q], (r1[q] - r1[-q]) * xg[q]
-            const f2 s35 = (f2{r1p, r2p} + f2{r1m, r2m}) * f2{g[q], g[q]};       // (r1[q] + r1[-q]) * g[q],  (r2[q] + r2[-q]) * g[q]
-            b2 += (double)d26.x;
-            b3 += (double)s35.x;
-            b6 += (double)d26.y;
-            b5 += (double)s35.y;
+            b2 += (double)((r0p - r0m) * xg[q]);
+            b3 += (double)((r1p + r1m) * g[q]);
+            b6 += (double)((r1p - r1m) * xg[q]);
+            b5 += (double)((r2p + r2m) * g[q]);
         }
 #endif
         float* o = outb[par] + x * 5;
