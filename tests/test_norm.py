@@ -74,7 +74,7 @@ def test_classifier_stack_end_to_end(ctx):
     assert prob.shape == (2, 1000) and np.all(prob.argmax(axis=1) == logits.argmax(axis=1))
 
 
-@pytest.mark.parametrize("rows,cols", [(3, 4), (2, 1000), (1, 1000), (7, 33), (1, 1)])
+@pytest.mark.parametrize("rows,cols", [(3, 4), (2, 1000), (1, 1000), (7, 36), (1, 4), (5, 100)])
 def test_host_softmax_on_a_fresh_context(rows, cols):
     """host operands are staged through a device buffer whose size must come from the SAME expressions as its
     layout (gamma | beta | pad to 64 floats | x rounded up to 256 bytes | y).  Round 3 reserved 2 * bytes + 8 * cols + 256 B, less than
@@ -92,3 +92,5 @@ def test_host_softmax_on_a_fresh_context(rows, cols):
         np.testing.assert_allclose(gb, torch.softmax(torch.from_numpy(big), dim=1).numpy(), rtol=2e-6, atol=1e-9)
         got2, _ = c.softmax(x)
         assert np.array_equal(got, got2)
+        with pytest.raises(Exception):                             # unsupported widths fail cleanly (cols: a multiple of 4 in 4 .. 4096)
+            c.softmax(np.zeros((2, 33), np.float32))
