@@ -834,6 +834,12 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 15; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
+    if (std::strcmp(name, "cnn_fuse") == 0) { ctx->cnn_fuse = value != 0; return AVD_OK; }
+    if (std::strcmp(name, "cnn_chunk") == 0) {
+        if (value < 1 || value > 1024) { ctx->err = "cnn_chunk: 1 ... 1024 frames per forward pass"; return AVD_ERR_ARG; }
+        ctx->cnn_chunk = value;
+        return AVD_OK;
+    }
     ctx->err = std::string("unknown option: ") + name;
     return AVD_ERR_ARG;
 }
@@ -848,6 +854,8 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_fold_up") == 0) { *value = ctx->fb_fold_up; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { *value = ctx->cnn_tiles; return AVD_OK; }
+    if (std::strcmp(name, "cnn_fuse") == 0) { *value = ctx->cnn_fuse; return AVD_OK; }
+    if (std::strcmp(name, "cnn_chunk") == 0) { *value = ctx->cnn_chunk; return AVD_OK; }
     if (std::strcmp(name, "rerun_pairs") == 0) { *value = ctx->last_rerun; return AVD_OK; }
     ctx->err = std::string("unknown option: ") + name;
     return AVD_ERR_ARG;
@@ -874,7 +882,9 @@ static int impl_cnn_forward(avd_ctx* ctx, const uint8_t* bgr, int mem, int n, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Workspace& ws = ctx->ws;
     if (!ws.d_cnn_w) { ctx->err = "avd_cnn_set_weights has not been called"; return AVD_ERR_ARG; }
-    constexpr int kChunk = 128;                        // frames per forward pass: bounds the activation scratch (4 x 206 MB)
+    // frames per forward pass: bounds the activation scratch (4 x 1.6 MB per frame); avd_set_option "cnn_chunk", 1 ... 1024
+    // (32-bit byte offsets inside an activation); the late stages fill the chip better with more frames per pass
+    const int kChunk = ctx->cnn_chunk;
     if (int e = cnn_reserve(ctx, std::min(n, kChunk))) return e;
     const uint8_t* d_bgr = nullptr;
     const size_t bytes = (size_t)frame_stride * (n - 1) + (size_t)row_stride * (h - 1) + (size_t)w * 3;

@@ -22,6 +22,7 @@
 // Tile: 256 pixels x (64 | 128 | 256) output channels per 512-thread workgroup, K in half stages of 32, ring of four half
 // stages with counted vmcnt + raw s_barrier (the scheme of avd_vit.hip; K is a run-time value here).
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "avd_internal.h"
 #include "avd_mfma_device.h"
@@ -205,6 +206,303 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
             pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
             pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + boff + loff) = pk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A bottleneck block's 3x3 convolution AND its expanding 1x1 in one kernel ("conv2 + conv3"): the 3x3's output tile
+// (BM pixels x all `mid` channels) never leaves the CU.  The expanding layers are the slowest of the unfused network
+// (K = mid is short: they move a residual and an output four times the size of their input and multiply little:
+// 140-260 TFLOP/s); fused, their operand comes from LDS, their residual reads and output stores overlap the NEXT
+// workgroup's 3x3 on the same CU, and the mid activation's write + read (2 x 48 MB per block at 56 x 56) disappears.
+//   1. the 3x3 exactly as k_conv_bf16 (same ring, same K order: same bits), BN = mid, one column tile;
+//   2. its epilogue (bias, ReLU, bf16) goes to LDS in the operand layout (KS2 half tiles of BM rows x 64 B) and every
+//      wave takes the fragments of ITS pixel rows into registers (KS2 x TI fragments) -- the ring is free again;
+//   3. the expanding 1x1 in NCH = 4 chunks of BN output channels: W3's chunk (BN x mid, one contiguous piece of the
+//      blocked weight) is copied into one of two LDS buffers by LDS-DMA while the previous chunk multiplies; epilogue
+//      = k_conv_bf16's (bias + residual + ReLU -> 16-byte stores into the blocked layout), the residual loads of a chunk
+//      are issued before its MFMAs.  Same k order as the unfused layer: the result is bit-identical to conv2 -> conv3.
+template <int BM, int WAVES_M, int TI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv3_expand(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W2,
+                                                     const float* __restrict__ bias2, const uint16_t* __restrict__ W3,
+                                                     const float* __restrict__ bias3, const uint16_t* __restrict__ R,
+                                                     uint16_t* __restrict__ Y, ConvGeom g)
+{
+    constexpr int KS = 3, WAVES_N = 8 / WAVES_M, TJ = 4, BN = WAVES_N * 64;
+    static_assert(WAVES_M * TI * 16 == BM, "tile rows");
+    constexpr int RA = BM / 8, QA = RA / 16, RB = BN / 8, QB = (RB + 15) / 16, P = QA + QB;
+    constexpr int HALF_A = BM * 64, HALF_B = BN * 64, STAGE = HALF_A + HALF_B, RING = 4 * STAGE;
+    constexpr int KS2 = BN / 32;                            // k steps of the expanding layer (K = mid = BN)
+    constexpr int A2 = BM * BN * 2, B2 = BN * BN * 2;       // bytes: the mid tile; one chunk of W3
+    constexpr int NBLK = (BN / 16) * KS2;                   // KiB blocks of one W3 chunk
+    static_assert(A2 + B2 <= RING && 2 * B2 <= RING && NBLK % 8 == 0, "the expand's buffers live in the 3x3's ring");
+    constexpr int NCH = 4;
+    extern __shared__ __align__(16) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int total = (g.m_out + BM - 1) / BM;
+    const int per = (gridDim.x + 7) >> 3;
+    const int lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lid >= total) return;
+    const int m0 = lid * BM;
+    // The expanding layer's bias is fetched NOW, before the first LDS-DMA enters the in-order vector-memory queue (one element per
+    // thread, parked in LDS after the 3x3): a load issued inside the chunk loop would make the compiler wait for everything in
+    // flight around it.
+    static_assert(NCH * BN <= 512, "one bias3 element per thread");
+    float b3v = threadIdx.x < NCH * BN ? bias3[threadIdx.x] : 0.f;
+
+    int rin0[QA], cw[QA];
+    unsigned tapmask[QA];
+    const int hw = g.hout * g.wout;
+#pragma unroll
+    for (int q = 0; q < QA; q++) {
+        const int r = wave * RA + q * 16 + (lane >> 2), m = m0 + r;
+        const bool valid = m < g.m_out;
+        const int img = m / hw, rem = m - img * hw, oy = rem / g.wout, ox = rem - oy * g.wout;
+        cw[q] = (lane & 3) ^ swz((r >> 2) & 3);
+        const int y0 = oy * g.stride - g.pad, x0 = ox * g.stride - g.pad;
+        rin0[q] = (img * g.hin + y0) * g.win + x0;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < KS * KS; t++) {
+            const int yi = y0 + t / KS, xi = x0 + t % KS;
+            if (valid && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win) mk |= 1u << t;
+        }
+        tapmask[q] = mk;
+    }
+    unsigned vob[QB];
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+        const int r = wave * RB + q * 16 + (lane >> 2);
+        vob[q] = (unsigned)((r >> 4) * g.nh * 1024 + (r & 15) * 64 + (lane & 3) * 16);
+    }
+    const char* xb = reinterpret_cast<const char*>(X);
+    int is_cb = 0, is_dy = 0, is_dx = 0;
+    auto issue = [&](int hs) __attribute__((always_inline)) {
+        char* st = lds + (hs & 3) * STAGE;
+#pragma unroll
+        for (int q = 0; q < QA; q++) {
+            const int rin = rin0[q] + is_dy * g.win + is_dx;
+            const bool ok = (tapmask[q] >> (is_dy * KS + is_dx)) & 1u;
+            unsigned off = (unsigned)(kZeroPage * 2) + (unsigned)((rin >> 4) * g.cpb + is_cb) * 1024u + (unsigned)((rin & 15) * 64) +
+                           (unsigned)((cw[q] ^ swz((rin >> 2) & 3)) << 4);
+            off = ok ? off : (unsigned)(lane * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * RA + q * 16) * 64), 16, 0, 0);
+        }
+        const char* wb = reinterpret_cast<const char*>(W2 + (int64_t)hs * 512);
+#pragma unroll
+        for (int q = 0; q < QB; q++) {
+            char* dst = st + HALF_A + (wave * RB + q * 16) * 64;
+            if (q * 16 + 16 <= RB) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + vob[q]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else if (lane < 32) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + vob[q]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+        if (++is_cb == g.cpb) {
+            is_cb = 0;
+            if (++is_dx == KS) { is_dx = 0; ++is_dy; }
+        }
+    };
+
+    f32x4 acc[TI][TJ];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    auto b_row = [&](int j, int rho) __attribute__((always_inline)) {
+        return wn * 64 + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3);
+    };
+    const int chunk = lane >> 4, r16 = lane & 15;
+
+    asm volatile("" : "+v"(b3v));                            // it has arrived (as far as the compiler is concerned too) before the queue fills
+
+    // LDS after the 3x3.  W3 is RESIDENT when all of it fits beside the mid tile (mid = 64: 32 KiB in one go, no barrier in the
+    // chunk loop); otherwise its chunks alternate between two buffers, the second of which takes over the mid tile's LDS once
+    // the fragments are in registers.  W3 (its first chunk) and the first residuals are requested during the 3x3's LAST step,
+    // into ring slots that step no longer reads: the last step reads slot (nh - 1) & 3 only (checked by the launcher).
+    //   resident (nh & 3 == 2, slot 1 live):  mid tile [0, A2) | W3 [2 STAGE, + NCH B2) | bias3 behind it
+    //   otherwise (nh & 3 == 0, slot 3 live): W3 chunk c at (c & 1) B2 | mid tile [B2, B2 + A2) | bias3 behind the ring
+    constexpr bool RESIDENT = NCH * B2 + NCH * BN * 4 <= 2 * STAGE && A2 <= 2 * STAGE;
+    static_assert(RESIDENT ? (2 * STAGE + NCH * B2 + NCH * BN * 4 <= RING) : (B2 + A2 <= RING && 2 * B2 <= RING && B2 <= 2 * STAGE), "LDS plan");
+    constexpr int W3BASE = RESIDENT ? 2 * STAGE : 0, A2BASE = RESIDENT ? 0 : B2;
+    constexpr int NRES = TI * TJ / 2;                       // residual loads (= output stores) per wave and chunk
+    char* const a2 = lds + A2BASE;
+    float* const lbias3 = reinterpret_cast<float*>(lds + (RESIDENT ? W3BASE + NCH * B2 : RING));
+    auto issue_w3 = [&](int c) __attribute__((always_inline)) {
+        char* buf = lds + W3BASE + (RESIDENT ? c : (c & 1)) * B2;
+        const char* src = reinterpret_cast<const char*>(W3) + (size_t)c * NBLK * 1024 + lane * 16;
+#pragma unroll
+        for (int t0 = 0; t0 < NBLK; t0 += 8) {
+            const int t = t0 + wave, rbl = t / KS2, kb = t % KS2;     // block t of the chunk: 16 weight rows x 32 k
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + t * 1024),
+                                             (__attribute__((address_space(3))) void*)(buf + kb * (BN * 64) + rbl * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned loff = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ swz((lane >> 2) & 3)) << 4));
+    const int cblocks = (NCH * BN) >> 5;
+    uint4 rv[2][TI][TJ / 2];                                 // residuals: the chunk being finished and the next one (in flight)
+    // byte offset of this lane's 16 bytes of output piece (chunk c, row tile i, column pair jp): 32-bit (an activation is < 4 GiB)
+    const unsigned obase = (unsigned)(kZeroPage * 2) + (unsigned)(((m0 >> 4) + wm * TI) * cblocks + wn * 2) * 1024u + loff;
+    auto out_off = [&](int c, int i, int jp) __attribute__((always_inline)) {
+        return obase + (unsigned)((i * cblocks + c * (BN >> 5) + jp) * 1024);
+    };
+    // PF: a chunk's residuals are requested one chunk ahead (two register sets); without it (the 128-channel shape, whose
+    // fragments of the mid tile take 32 registers) at the top of their own chunk, in front of its MFMAs
+    constexpr bool PF = RESIDENT;
+    auto load_res = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int jp = 0; jp < TJ / 2; jp++)
+                rv[PF ? (c & 1) : 0][i][jp] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(R) + out_off(c, i, jp));
+    };
+
+    // ---- 1. the 3x3 (the loop of k_conv_bf16)
+    const int nh = g.nh;
+    auto step = [&](int hs, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        const int younger = (hs + 2 < nh - 1 ? hs + 2 : nh - 1) - hs;
+        if (LAST) AVD_WAIT_VMC(0);
+        else if (younger >= 2) AVD_WAIT_VMC(2 * P);
+        else if (younger == 1) AVD_WAIT_VMC(P);
+        else AVD_WAIT_VMC(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (LAST) {                                          // everyone is past step nh - 2: three ring slots are free
+            if (RESIDENT) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) issue_w3(c);
+            } else {
+                issue_w3(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PF) load_res(0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (hs + 3 < nh) {
+            issue(hs + 3);
+        }
+        const char* cur = lds + (hs & 3) * STAGE;
+        bf16x8 a[TI], b[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; j++) b[j] = frag(cur + HALF_A, b_row(j, r16), chunk);
+#pragma unroll
+        for (int i = 0; i < TI; i++) a[i] = frag(cur, (wm * TI + i) * 16 + r16, chunk);
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    };
+    for (int hs = 0; hs < 3; hs++) issue(hs);                // nh >= 18
+    for (int hs = 0; hs < nh - 1; hs++) step(hs, std::false_type{});
+    step(nh - 1, std::true_type{});
+
+    // ---- 2. the mid tile -> LDS (operand layout) -> this wave's fragments
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // every wave has read its last fragments: the whole ring is free
+    __builtin_amdgcn_sched_barrier(0);
+    // the 3x3's bias: this lane's 16 values.  (The compiler puts a vmcnt(0) in front of the LDS stores below anyway, because
+    // LDS-DMAs are in flight -- W3 and the first chunk of residuals have had the last step to arrive -- so this load costs no
+    // extra wait.)
+    f32x4 b2lo[TJ / 2], b2hi[TJ / 2];
+#pragma unroll
+    for (int jp = 0; jp < TJ / 2; jp++) {
+        const float* pb = bias2 + wn * 64 + jp * 32 + (lane >> 4) * 8;
+        b2lo[jp] = *reinterpret_cast<const f32x4*>(pb);
+        b2hi[jp] = *reinterpret_cast<const f32x4*>(pb + 4);
+    }
+    if (threadIdx.x < NCH * BN) lbias3[threadIdx.x] = b3v;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int jp = 0; jp < TJ / 2; jp++) {
+            f32x4 lo = acc[i][2 * jp] + b2lo[jp];
+            f32x4 hi = acc[i][2 * jp + 1] + b2hi[jp];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+            pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+            *reinterpret_cast<uint4*>(a2 + (wn * 2 + jp) * (BM * 64) + (wm * TI + i) * 1024 + loff) = pk;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's part of W3 has landed, its part of the mid tile is written
+    __builtin_amdgcn_s_barrier();                            // ... and everybody else's
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 am[KS2][TI];
+#pragma unroll
+    for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+        for (int i = 0; i < TI; i++) am[ks][i] = frag(a2 + ks * (BM * 64), (wm * TI + i) * 16 + r16, chunk);
+    if (!RESIDENT) {                                         // the second W3 buffer takes over the mid tile's LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- 3. the expanding 1x1, BN output channels at a time.  Vector-memory queue of a wave (in order), resident W3: res(1) st(0) |
+    // res(2) st(1) | res(3) st(2) | st(3); otherwise res(c) DMA(c + 1) st(c) per chunk: the wait for DMA(c + 1) at the end of
+    // iteration c leaves the stores of chunk c in flight.
+    static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two (the residual buffers alternate)");
+#pragma unroll 1
+    for (int c2 = 0; c2 < NCH; c2 += 2)
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        const int c = c2 + cc;
+        if (!PF) load_res(c);
+        if (!RESIDENT && c + 1 < NCH) issue_w3(c + 1);
+        if (PF && c + 1 < NCH) load_res(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        zero_acc();
+        const char* buf = lds + W3BASE + (RESIDENT ? c : (c & 1)) * B2;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) {
+            bf16x8 b[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; j++) b[j] = frag(buf + ks * (BN * 64), b_row(j, r16), chunk);
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], am[ks][i], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int jp = 0; jp < TJ / 2; jp++) {
+                const float* pb = lbias3 + c * BN + wn * 64 + jp * 32 + (lane >> 4) * 8;
+                f32x4 lo = acc[i][2 * jp] + *reinterpret_cast<const f32x4*>(pb);
+                f32x4 hi = acc[i][2 * jp + 1] + *reinterpret_cast<const f32x4*>(pb + 4);
+                const uint4 r = rv[PF ? (c & 1) : 0][i][jp];
+                lo[0] += bf16_to_f32(r.x & 0xFFFF); lo[1] += bf16_to_f32(r.x >> 16);
+                lo[2] += bf16_to_f32(r.y & 0xFFFF); lo[3] += bf16_to_f32(r.y >> 16);
+                hi[0] += bf16_to_f32(r.z & 0xFFFF); hi[1] += bf16_to_f32(r.z >> 16);
+                hi[2] += bf16_to_f32(r.w & 0xFFFF); hi[3] += bf16_to_f32(r.w >> 16);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+                pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + out_off(c, i, jp)) = pk;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!RESIDENT && c + 1 < NCH) {
+            AVD_WAIT_VMC((PF ? 2 : 1) * NRES);               // younger than DMA(c + 1): [res(c + 1),] st(c)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // the next chunk has landed for every wave; everyone is done reading this one
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -401,6 +699,35 @@ int launch_conv(avd_ctx* ctx, const uint16_t* x, const uint16_t* w, const float*
     return go(k_conv_bf16<256, 8, 2, 0, 1>, 256, 64);
 }
 
+// conv2 (3x3, mid -> mid, stride s, ReLU) + conv3 (1x1, mid -> 4 mid, + residual, ReLU) of a bottleneck block in one launch
+// (k_conv3_expand); mid = 64 (256-pixel tiles) or 128 (128-pixel tiles).  y must not be the 3x3's input.
+bool can_fuse_expand(int mid) { return mid == 64 || mid == 128; }
+int launch_conv3_expand(avd_ctx* ctx, const uint16_t* x, const uint16_t* w2, const float* b2, const uint16_t* w3, const float* b3,
+                        const uint16_t* res, uint16_t* y, int n, int hin, int win, int mid, int stride)
+{
+    ConvGeom g;
+    g.hin = hin; g.win = win; g.cin = mid; g.cout = mid; g.ksize = 3; g.stride = stride; g.pad = 1;
+    g.hout = (hin + 2 - 3) / stride + 1;
+    g.wout = (win + 2 - 3) / stride + 1;
+    g.m_out = n * g.hout * g.wout;
+    g.cpb = mid / 32;
+    g.nh = 9 * g.cpb;
+    if (!can_fuse_expand(mid) || !res || y == x) { ctx->err = "conv3_expand: mid 64 or 128, a residual, output apart from the input"; return AVD_ERR_ARG; }
+    auto go = [&](auto kern, int bm, int bn) -> int {
+        const int total = (g.m_out + bm - 1) / bm, grid = (total + 7) / 8 * 8;
+        // the ring; W3 resident (mid = 64): the expanding layer's bias fits inside it, otherwise behind it.  The kernel's LDS plan
+        // assumes which ring slot the 3x3's last step reads: nh & 3 == 2 (mid = 64: 18 half stages) or 0 (mid = 128: 36)
+        if ((g.nh & 3) != (bn == 64 ? 2 : 0)) { ctx->err = "conv3_expand: ring phase"; return AVD_ERR_ARG; }
+        const size_t lds = (size_t)4 * (size_t)(bm * 64 + bn * 64) + (bn == 64 ? 0 : (size_t)bn * 4 * sizeof(float));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, x, w2, b2, w3, b3, res, y, g);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
+    if (mid == 64) return go(k_conv3_expand<256, 8, 2>, 256, 64);
+    return go(k_conv3_expand<128, 4, 2>, 128, 128);
+}
+
 size_t act_elems(size_t rows, int c) { return kZeroPage + (rows + 255) / 256 * 256 * (size_t)c; }
 
 }  // namespace
@@ -487,16 +814,22 @@ int launch_cnn_forward(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, 
             const int t1 = (cur + 1) & 3, t2 = (cur + 2) & 3, sc = (cur + 3) & 3;
             uint16_t *x = ws.d_cnn_act[cur], *a1 = ws.d_cnn_act[t1], *a2 = ws.d_cnn_act[t2], *a3 = ws.d_cnn_act[sc];
             if (int e = launch_conv(ctx, x, wptr(li), bptr(li), nullptr, a1, n, hgt, hgt, cin, mid, 1, 1, 1)) return e;
-            if (int e = launch_conv(ctx, a1, wptr(li + 1), bptr(li + 1), nullptr, a2, n, hgt, hgt, mid, mid, 3, s, 1)) return e;
             const int ho = hgt / s;
             const uint16_t* res = x;
-            if (b == 0) {                                    // projection shortcut into a3, then conv3 writes over a1
+            if (b == 0) {                                    // projection shortcut into a3
                 if (int e = launch_conv(ctx, x, wptr(li + 3), bptr(li + 3), nullptr, a3, n, hgt, hgt, cin, out, 1, s, 0)) return e;
                 res = a3;
             }
-            if (int e = launch_conv(ctx, a2, wptr(li + 2), bptr(li + 2), res, a1, n, ho, ho, mid, out, 1, 1, 1)) return e;
+            if (ctx->cnn_fuse && can_fuse_expand(mid)) {     // conv2 + conv3 in one launch: a1 -> a2 (other workgroups still read a1's halo)
+                if (int e = launch_conv3_expand(ctx, a1, wptr(li + 1), bptr(li + 1), wptr(li + 2), bptr(li + 2), res, a2, n, hgt, hgt, mid, s)) return e;
+                cur = t2;
+            } else {                                         // conv3 writes over a1
+                if (int e = launch_conv(ctx, a1, wptr(li + 1), bptr(li + 1), nullptr, a2, n, hgt, hgt, mid, mid, 3, s, 1)) return e;
+                if (int e = launch_conv(ctx, a2, wptr(li + 2), bptr(li + 2), res, a1, n, ho, ho, mid, out, 1, 1, 1)) return e;
+                cur = t1;
+            }
             li += b == 0 ? 4 : 3;
-            cur = t1; hgt = ho; cin = out;
+            hgt = ho; cin = out;
         }
     }
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n * 256 + 255) / 256)), dim3(256), 0, ctx->stream, ws.d_cnn_act[cur], n, 49, 2048, ws.d_cnn_pool);

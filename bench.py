@@ -233,6 +233,8 @@ def compact_line(full, details_path=None):
                        ("roofline_nv12_ingest", "nv12_ingest")):
         if full.get(key):
             ext[short] = pick(full[key], ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "forward_ms", "hbm_traffic_bytes_per_forward"))
+            if key == "mfma_cnn_forward" and full[key].get("four_clips_per_pass"):
+                ext[short]["frac_four_clips_per_pass"] = full[key]["four_clips_per_pass"]["frac"]
     if full.get("audio_analyzer"):
         ext["audio"] = pick(full["audio_analyzer"], ("gpu_call_ms", "windows"))
     if ext:
@@ -678,8 +680,20 @@ def main():
         ctxs[0].cnn_forward(frames[0], timing_reps=1)
         logits, fwd_ms = ctxs[0].cnn_forward(frames[0], timing_reps=5)
         cnn = {"frames": int(frames[0].shape[0]), "forward_ms": fwd_ms, "macs_per_frame": host_cnn.macs_per_frame(),
-               "top1_head": [int(v) for v in logits[:3].argmax(axis=1)]}
-        del wts, bss
+               "top1_head": [int(v) for v in logits[:3].argmax(axis=1)], "fused": int(ctxs[0].get_option("cnn_fuse"))}
+        # the same network layer by layer (A/B of the fused blocks), and four clips per forward pass (the 14x14 / 7x7 stages have
+        # too few pixels per 120 frames to fill 256 CUs with large tiles)
+        ctxs[0].set_option("cnn_fuse", 0)
+        ctxs[0].cnn_forward(frames[0], timing_reps=1)
+        _, cnn["forward_ms_layer_by_layer"] = ctxs[0].cnn_forward(frames[0], timing_reps=5)
+        ctxs[0].set_option("cnn_fuse", 1)
+        four = torch.cat([frames[0]] * 4)
+        ctxs[0].set_option("cnn_chunk", int(four.shape[0]))
+        ctxs[0].cnn_forward(four, timing_reps=1)
+        _, cnn["forward_ms_four_clips"] = ctxs[0].cnn_forward(four, timing_reps=3)
+        cnn["frames_four_clips"] = int(four.shape[0])
+        ctxs[0].set_option("cnn_chunk", 128)
+        del wts, bss, four
 
     # LayerNorm over the patch-embed tokens and softmax over the CNN's logits (north_star's stack; extensions, reported apart)
     norm = None
@@ -934,25 +948,35 @@ def main():
         if cnn is not None:
             fl = 2.0 * cnn["macs_per_frame"] * cnn["frames"]
             tf = fl / (cnn["forward_ms"] * 1e-3) / 1e12
-            cnn_traffic = None
+            cnn_traffic, cnn_traffic_file = None, None
             try:
-                ext = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_extensions.json")))
-                if cnn["frames"] == 120:
-                    cnn_traffic = ext["cnn_forward_120_frames"]["hbm_bytes"]
+                for name in ("r04_pmc_extensions.json", "r02_pmc_extensions.json"):
+                    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+                    if os.path.exists(path):
+                        ext = json.load(open(path))
+                        if cnn["frames"] == 120:
+                            cnn_traffic = ext["cnn_forward_120_frames"]["hbm_bytes"]
+                            cnn_traffic_file = "profiles/" + name
+                        break
             except (OSError, KeyError, ValueError):
                 pass
+            tf4 = 2.0 * cnn["macs_per_frame"] * cnn["frames_four_clips"] / (cnn["forward_ms_four_clips"] * 1e-3) / 1e12
             out["mfma_cnn_forward"] = {
-                "kernel": "k_conv_bf16 x 53 (ResNet-50-style forward: every convolution one implicit GEMM, the activation operand gathered by "
-                          "LDS-DMA from blocked + swizzled bf16 activations, bias / residual / ReLU fused; the 7x7 stem gathers pixel pairs from a zero-bordered input image) + input conversion, max / average pooling, linear",
+                "kernel": "k_conv_bf16 + k_conv3_expand (ResNet-50-style forward: every convolution one implicit GEMM, the activation operand gathered by "
+                          "LDS-DMA from blocked + swizzled bf16 activations, bias / residual / ReLU fused; in the 56x56 and 28x28 stages a block's 3x3 and its "
+                          "expanding 1x1 are ONE launch with the mid activation in LDS; the 7x7 stem gathers pixel pairs from a zero-bordered input image) + input conversion, max / average pooling, linear",
                 "extension": "no reference counterpart (the reference has no learned model); seeded random weights; not part of value / ai_score",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                 "frames_per_forward": cnn["frames"], "gmac_per_frame": round(cnn["macs_per_frame"] / 1e9, 3),
                 "forward_ms": round(cnn["forward_ms"], 3), "frames_per_s": round(cnn["frames"] / (cnn["forward_ms"] * 1e-3), 1),
-                "launches_per_forward": 57, "top1_head": cnn["top1_head"],
-                "hbm_traffic_bytes_per_forward": cnn_traffic,
+                "launches_per_forward": 50 if cnn["fused"] else 57, "top1_head": cnn["top1_head"],
+                "forward_ms_layer_by_layer": round(cnn["forward_ms_layer_by_layer"], 3),
+                "four_clips_per_pass": {"frames": cnn["frames_four_clips"], "forward_ms": round(cnn["forward_ms_four_clips"], 3),
+                                        "achieved": round(tf4, 1), "frac": round(tf4 / 2500.0, 4)},
+                "hbm_traffic_bytes_per_forward": cnn_traffic, "hbm_traffic_from_profiles": cnn_traffic_file,
                 "hbm_gbps": None if cnn_traffic is None else round(cnn_traffic / (cnn["forward_ms"] * 1e-3) / 1e9, 1),
-                "hbm_note": "PMC traffic (profiles/r02_pmc_extensions.json, 120 frames): bf16 activations written and read once per layer are "
-                            "63 MB per frame -- a layer-by-layer forward is bound by this traffic (~1.5 ms per 120 frames at 5 TB/s), not by the matrix pipe",
+                "hbm_note": "PMC traffic of 120 frames: bf16 activations written and read once per layer were 63 MB per frame layer by layer (round 2); "
+                            "what bounds a layer is the per-CU L2 -> LDS ingest (~40 GB/s per CU, tools/ldsdma_bench.hip), see profiles/r04_experiments.md section 5",
                 "timed": "5 whole forward passes (BGR frames in HBM to logits) between two HIP events on the library's stream"}
         if norm is not None:
             lnb = norm["rows"] * 768 * 4                             # bf16 tokens read once and written once

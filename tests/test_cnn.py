@@ -224,6 +224,24 @@ def test_every_tiling_gives_the_same_bits(ctx):
 
 
 @pytest.mark.gpu
+def test_fused_blocks_give_the_same_bits(ctx):
+    """A block's 3x3 + expanding 1x1 in one launch (k_conv3_expand, stages 1 and 2; the default) accumulates every output's K
+    terms in the order of the two separate layers and rounds the mid activation to bf16 at the same place: identical logits."""
+    weights, biases = seeded_parameters(0)
+    ctx.cnn_set_weights(weights, biases)
+    frames = synth.random_frames(5, 96, 128, seed=21)
+    assert ctx.get_option("cnn_fuse") == 1
+    try:
+        fused, _ = ctx.cnn_forward(frames)
+        ctx.set_option("cnn_fuse", 0)
+        plain, _ = ctx.cnn_forward(frames)
+    finally:
+        ctx.set_option("cnn_fuse", 1)
+    assert np.isfinite(fused).all() and float(np.abs(fused).max()) > 0
+    assert np.array_equal(fused, plain)
+
+
+@pytest.mark.gpu
 def test_forward_in_passes_of_128_frames(ctx):
     """More frames than one pass holds: the second pass reuses every scratch buffer; frames repeat, so must the logits."""
     weights, biases = seeded_parameters(0)

@@ -14,6 +14,9 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 clip = synth.random_frames(4, 360, 640, seed=1)
 frames = torch.from_numpy(np.concatenate([clip] * (n // 4))).to("cuda:0")
 ctx = avd_hip.Context(0)
+ctx.set_option("cnn_chunk", int(os.environ.get("AVD_CNN_CHUNK", "128")))     # frames per forward pass
+if os.environ.get("AVD_CNN_FUSE"):
+    ctx.set_option("cnn_fuse", int(os.environ["AVD_CNN_FUSE"]))
 ctx.cnn_set_weights(*cnn.seeded_parameters(0))
 logits, ms = ctx.cnn_forward(frames, timing_reps=reps)
 print("forward %.3f ms for %d frames" % (ms, n))
