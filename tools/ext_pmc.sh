@@ -9,4 +9,4 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/ext_pmc_write_cn
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/ext_pmc_fetch_vit -- python3 $R/tools/run_vit.py 960 2 >> $R/gpurun_out/ext_pmc.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/ext_pmc_write_vit -- python3 $R/tools/run_vit.py 960 2 >> $R/gpurun_out/ext_pmc.log 2>&1 || exit 1
 cd $R
-python tools/ext_pmc_summary.py
+python tools/ext_pmc_summary.py 50 r04_pmc_extensions.json && cp gpurun_out/r04_pmc_extensions.json profiles/r04_pmc_extensions.json   # bench.py reads the CNN traffic from here

@@ -22,6 +22,8 @@ echo pmc done
 cd $R
 python tools/pmc_to_json.py gpurun_out/r04_pmc.json "round 4 (default mode: fast level kernels + re-run)" gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_sq gpurun_out/r04_pmc_ta > gpurun_out/r04_pmc_summary.txt
 mkdir -p profiles && cp gpurun_out/r04_pmc.json profiles/r04_pmc.json     # bench.py reads the traffic figures and the busy fractions from here
+bash tools/ext_pmc.sh > gpurun_out/r04_ext_pmc.txt 2>&1 || echo "extension pmc failed"
+bash tools/cnn_profile.sh > gpurun_out/r04_cnn_layers.txt 2>&1 || echo "cnn layer trace failed"
 python bench.py --details gpurun_out/r04_bench_details.json > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err || exit 1
 python bench.py --inflight 1 --cpu-frames 0 --no-extras --no-vit --details gpurun_out/r04_bench_inflight1_details.json > gpurun_out/r04_bench_inflight1.json 2>> gpurun_out/r04_bench.err || exit 1
 AVD_BENCH_DEVICE=0 python bench.py --gpus 2 --backend gloo --cpu-frames 0 --no-extras --no-vit --no-pcie --repeats 3 > gpurun_out/r04_rehearsal_2ranks_1gpu_gloo.json 2> gpurun_out/r04_rehearsal.err || echo "rehearsal failed"
