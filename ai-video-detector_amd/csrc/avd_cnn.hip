@@ -201,10 +201,10 @@ __global__ __launch_bounds__(512) void k_conv_bf16(const uint16_t* __restrict__ 
                 for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
             }
             uint4 pk;
-            pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-            pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+            pk.x = pack_bf16x2(lo[0], lo[1]);
+            pk.y = pack_bf16x2(lo[2], lo[3]);
+            pk.z = pack_bf16x2(hi[0], hi[1]);
+            pk.w = pack_bf16x2(hi[2], hi[3]);
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + boff + loff) = pk;
         }
     }
@@ -430,10 +430,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
             uint4 pk;
-            pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-            pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+            pk.x = pack_bf16x2(lo[0], lo[1]);
+            pk.y = pack_bf16x2(lo[2], lo[3]);
+            pk.z = pack_bf16x2(hi[0], hi[1]);
+            pk.w = pack_bf16x2(hi[2], hi[3]);
             *reinterpret_cast<uint4*>(a2 + (wn * 2 + jp) * (BM * 64) + (wm * TI + i) * 1024 + loff) = pk;
         }
     __builtin_amdgcn_sched_barrier(0);
@@ -491,10 +491,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
                 uint4 pk;
-                pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-                pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-                pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+                pk.x = pack_bf16x2(lo[0], lo[1]);
+                pk.y = pack_bf16x2(lo[2], lo[3]);
+                pk.z = pack_bf16x2(hi[0], hi[1]);
+                pk.w = pack_bf16x2(hi[2], hi[3]);
                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + out_off(c, i, jp)) = pk;
             }
         __builtin_amdgcn_sched_barrier(0);

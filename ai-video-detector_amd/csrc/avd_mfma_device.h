@@ -19,6 +19,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float v)
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);       // round to nearest even (inputs are finite)
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+// two floats -> two bf16 in one dword (lo in bits 0-15): gfx950's v_cvt_pk_bf16_f32, round to nearest even -- the same bits as
+// f32_to_bf16 for finite inputs, one instruction instead of eight
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    const bf16x2_t r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, r);
+}
 
 // Bank swizzle of a half tile (64-byte rows, four 16-byte chunks per row, four rows per 256-byte bank row): chunk c of
 // row r sits in slot c ^ swz((r >> 2) & 3).  A ds_read_b128 is served in groups of 16 lanes that are NOT contiguous

@@ -193,10 +193,10 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
                 if (row0 + (lane & 15) < M && !(DBG & 4)) {
                     if (OUT_BF16) {
                         uint4 pk;
-                        pk.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-                        pk.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-                        pk.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-                        pk.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+                        pk.x = pack_bf16x2(lo[0], lo[1]);
+                        pk.y = pack_bf16x2(lo[2], lo[3]);
+                        pk.z = pack_bf16x2(hi[0], hi[1]);
+                        pk.w = pack_bf16x2(hi[2], hi[3]);
                         *reinterpret_cast<uint4*>(piece + coff) = pk;
                     } else {
                         *reinterpret_cast<f32x4*>(piece + coff) = lo;
