@@ -834,7 +834,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 15; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
-    if (std::strcmp(name, "cnn_fuse") == 0) { ctx->cnn_fuse = value != 0; return AVD_OK; }
+    if (std::strcmp(name, "cnn_fuse") == 0) { ctx->cnn_fuse = value < 0 ? 0 : (value > 2 ? 2 : value); return AVD_OK; }
     if (std::strcmp(name, "cnn_chunk") == 0) {
         if (value < 1 || value > 1024) { ctx->err = "cnn_chunk: 1 ... 1024 frames per forward pass"; return AVD_ERR_ARG; }
         ctx->cnn_chunk = value;

@@ -507,6 +507,223 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fused block for mid = 64, stride 1 (the 56 x 56 stage) with the 3x3's input as ONE slab in LDS.  k_conv3_expand
+// gathers the 256 output pixels' inputs from L2 once per tap: 9 x 32 KB of its 520 KB of ingest per workgroup, on a path that
+// delivers ~37-40 GB/s per CU whatever the instruction (profiles/r04_experiments.md section 5).  Output pixels m0 .. m0 + 255 of
+// the linear pixel index see, through the nine taps, input pixels m0 - 57 .. m0 + 312: the 384 pixels m0 - 64 .. m0 + 319 are
+// 24 pixel blocks x 2 channel blocks = 48 CONTIGUOUS KiB of the blocked activation, copied once (48 LDS-DMA instructions).  A tap
+// is then a fragment read at a shifted slab row -- lane (pixel r, chunk) reads row 64 + tile row + r + dy W + dx, which carries its
+// own swizzle key -- with the fragment zeroed where the tap leaves the image (a per-lane 9-bit mask).  Only the weights stream:
+// one tap (64 x 64 bf16 = 8 KB, one LDS-DMA instruction per wave) per step, ring of four, 16 MFMAs per wave between barriers.
+// Same K order (tap, then channel block) as the gathering kernels: bit-identical.  The expanding layer follows as in
+// k_conv3_expand (resident W3; it is requested after the last tap, when the slab is dead).
+template <int DUMMY>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slab3_expand(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W2,
+                                                     const float* __restrict__ bias2, const uint16_t* __restrict__ W3,
+                                                     const float* __restrict__ bias3, const uint16_t* __restrict__ R,
+                                                     uint16_t* __restrict__ Y, ConvGeom g, int in_blocks)
+{
+    constexpr int BM = 256, TI = 2, TJ = 4, BN = 64, KS2 = 2, NCH = 4;
+    constexpr int NSLAB = 384, SLAB = NSLAB * 128, TAPB = BN * 64 * 2, LDS = SLAB + 4 * TAPB;      // 48 KiB + 4 x 8 KiB = 80 KiB
+    constexpr int A2 = BM * BN * 2, B2 = BN * BN * 2, W3BASE = 0, A2BASE = NCH * B2;                // after the taps: W3 | mid tile | bias3
+    static_assert(A2BASE + A2 + NCH * BN * 4 <= LDS, "LDS plan of the expanding layer");
+    extern __shared__ __align__(16) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave;                                     // eight waves along the pixels, one column tile
+    const int total = (g.m_out + BM - 1) / BM;
+    const int per = (gridDim.x + 7) >> 3;
+    const int lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lid >= total) return;
+    const int m0 = lid * BM;
+    float b3v = threadIdx.x < NCH * BN ? bias3[threadIdx.x] : 0.f;
+    asm volatile("" : "+v"(b3v));                            // arrived before the queue fills (k_conv3_expand)
+    const int chunk = lane >> 4, r16 = lane & 15;
+    const char* xb = reinterpret_cast<const char*>(X);
+
+    // ---- the slab: pixel blocks (m0 >> 4) - 4 .. + 23, two channel blocks each; blocks outside the activation come from the zero page
+    // (their pixels are masked in every tap: they only must not fault)
+    const int blk0 = (m0 >> 4) - 4;
+#pragma unroll
+    for (int j0 = 0; j0 < 48; j0 += 8) {
+        const int j = j0 + wave, pb = blk0 + (j >> 1);
+        const bool ok = pb >= 0 && pb < in_blocks;          // wave-uniform
+        const char* src = ok ? xb + kZeroPage * 2 + ((size_t)pb * 2 + (j & 1)) * 1024 + lane * 16 : xb + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
+    }
+    // one tap of W2 = k blocks 2 t, 2 t + 1 of the four weight-row blocks: eight KiB blocks, one per wave
+    auto issue_tap = [&](int t) __attribute__((always_inline)) {
+        const int rb = wave >> 1, kbl = wave & 1;
+        const char* src = reinterpret_cast<const char*>(W2) + ((size_t)(rb * 18 + 2 * t + kbl)) * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + SLAB + (t & 3) * TAPB + kbl * (BN * 64) + rb * 1024), 16, 0, 0);
+    };
+    issue_tap(0); issue_tap(1); issue_tap(2);
+
+    // per-lane tap masks of this wave's two row tiles, and the slab row of tap (0, 0) - i.e. shift 0 - of each
+    unsigned tapmask[TI];
+    int qbase[TI];
+    const int hw = g.hout * g.wout;
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+        const int pl = (wm * TI + i) * 16 + r16, m = m0 + pl;
+        const bool valid = m < g.m_out;
+        const int img = m / hw, rem = m - img * hw, oy = rem / g.wout, ox = rem - oy * g.wout;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int yi = oy - 1 + t / 3, xi = ox - 1 + t % 3;
+            if (valid && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win) mk |= 1u << t;
+        }
+        tapmask[i] = mk;
+        qbase[i] = 64 + pl;
+    }
+    f32x4 acc[TI][TJ];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    auto b_row = [&](int j, int rho) __attribute__((always_inline)) { return (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3); };
+    const unsigned loff = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ swz((lane >> 2) & 3)) << 4));
+    constexpr int cblocks = (NCH * BN) >> 5;
+    uint4 rv[2][TI][TJ / 2];
+    const unsigned obase = (unsigned)(kZeroPage * 2) + (unsigned)(((m0 >> 4) + wm * TI) * cblocks) * 1024u + loff;
+    auto out_off = [&](int c, int i, int jp) __attribute__((always_inline)) { return obase + (unsigned)((i * cblocks + c * (BN >> 5) + jp) * 1024); };
+    auto load_res = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int jp = 0; jp < TJ / 2; jp++)
+                rv[c & 1][i][jp] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(R) + out_off(c, i, jp));
+    };
+
+    // ---- 1. the nine taps
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < 7) AVD_WAIT_VMC(2);                          // taps t + 1, t + 2 may still be in flight (the slab is older than tap 0)
+        else if (t == 7) AVD_WAIT_VMC(1);
+        else AVD_WAIT_VMC(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 3 < 9) issue_tap(t + 3);
+        else if (t == 8) load_res(0);                        // the first residuals, a whole step + the mid tile's epilogue ahead
+        __builtin_amdgcn_sched_barrier(0);
+        const int shift = (t / 3 - 1) * g.win + (t % 3 - 1);
+        const char* st = lds + SLAB + (t & 3) * TAPB;
+        bf16x8 a[TI][2], b[TJ][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int j = 0; j < TJ; j++) b[j][kb] = frag(st + kb * (BN * 64), b_row(j, r16), chunk);
+#pragma unroll
+            for (int i = 0; i < TI; i++) {
+                const int q = qbase[i] + shift;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + (q >> 4) * 2048 + kb * 1024 + (q & 15) * 64 + ((chunk ^ swz(((q & 15) >> 2) & 3)) << 4));
+                a[i][kb] = ((tapmask[i] >> t) & 1u) ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kb], a[i][kb], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- 2. W3 into the dead slab, the mid tile -> LDS -> this wave's fragments
+    char* const a2 = lds + A2BASE;
+    float* const lbias3 = reinterpret_cast<float*>(lds + A2BASE + A2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // every wave has read its last fragments
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 b2lo[TJ / 2], b2hi[TJ / 2];
+#pragma unroll
+    for (int jp = 0; jp < TJ / 2; jp++) {
+        const float* pb = bias2 + jp * 32 + (lane >> 4) * 8;
+        b2lo[jp] = *reinterpret_cast<const f32x4*>(pb);
+        b2hi[jp] = *reinterpret_cast<const f32x4*>(pb + 4);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {                          // W3: four chunks of 64 rows x 64 k = 8 KiB blocks each, one per wave
+        const int rbl = wave / KS2, kb = wave % KS2;
+        const char* src = reinterpret_cast<const char*>(W3) + ((size_t)c * 8 + wave) * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + W3BASE + c * B2 + kb * (BN * 64) + rbl * 1024), 16, 0, 0);
+    }
+    if (threadIdx.x < NCH * BN) lbias3[threadIdx.x] = b3v;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int jp = 0; jp < TJ / 2; jp++) {
+            f32x4 lo = acc[i][2 * jp] + b2lo[jp];
+            f32x4 hi = acc[i][2 * jp + 1] + b2hi[jp];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+            uint4 pk;
+            pk.x = pack_bf16x2(lo[0], lo[1]); pk.y = pack_bf16x2(lo[2], lo[3]);
+            pk.z = pack_bf16x2(hi[0], hi[1]); pk.w = pack_bf16x2(hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(a2 + jp * (BM * 64) + (wm * TI + i) * 1024 + loff) = pk;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // W3 and the mid tile are complete for everyone
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 am[KS2][TI];
+#pragma unroll
+    for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+        for (int i = 0; i < TI; i++) am[ks][i] = frag(a2 + ks * (BM * 64), (wm * TI + i) * 16 + r16, chunk);
+
+    // ---- 3. the expanding 1x1 (k_conv3_expand's resident form: no barrier in the loop)
+    static_assert(NCH % 2 == 0, "unrolled by two");
+#pragma unroll 1
+    for (int c2 = 0; c2 < NCH; c2 += 2)
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        const int c = c2 + cc;
+        if (c + 1 < NCH) load_res(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        zero_acc();
+        const char* buf = lds + W3BASE + c * B2;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) {
+            bf16x8 b[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; j++) b[j] = frag(buf + ks * (BN * 64), b_row(j, r16), chunk);
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], am[ks][i], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int jp = 0; jp < TJ / 2; jp++) {
+                const float* pb = lbias3 + c * BN + jp * 32 + (lane >> 4) * 8;
+                f32x4 lo = acc[i][2 * jp] + *reinterpret_cast<const f32x4*>(pb);
+                f32x4 hi = acc[i][2 * jp + 1] + *reinterpret_cast<const f32x4*>(pb + 4);
+                const uint4 r = rv[c & 1][i][jp];
+                lo[0] += bf16_to_f32(r.x & 0xFFFF); lo[1] += bf16_to_f32(r.x >> 16);
+                lo[2] += bf16_to_f32(r.y & 0xFFFF); lo[3] += bf16_to_f32(r.y >> 16);
+                hi[0] += bf16_to_f32(r.z & 0xFFFF); hi[1] += bf16_to_f32(r.z >> 16);
+                hi[2] += bf16_to_f32(r.w & 0xFFFF); hi[3] += bf16_to_f32(r.w >> 16);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+                uint4 pk;
+                pk.x = pack_bf16x2(lo[0], lo[1]); pk.y = pack_bf16x2(lo[2], lo[3]);
+                pk.z = pack_bf16x2(hi[0], hi[1]); pk.w = pack_bf16x2(hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + out_off(c, i, jp)) = pk;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // BGR uint8 frame -> 224 x 224 (float bilinear taps, cv2's INTER_LINEAR centre mapping), RGB, (x / 255 - mean) / std,
 // bf16: img[frame][y + 3][x + 3][4] of the zero-bordered 232 x 232 image (fourth channel zero; the border is cleared once,
 // when the buffer is allocated).  Same arithmetic as k_vit_patchify.
@@ -724,6 +941,16 @@ int launch_conv3_expand(avd_ctx* ctx, const uint16_t* x, const uint16_t* w2, con
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
+    if (mid == 64 && stride == 1 && ctx->cnn_fuse == 2) {
+        // the 3x3's input as one slab in LDS (k_slab3_expand); the blocks of the input activation that exist: its rows are padded to 256
+        const int in_blocks = (int)(((size_t)n * hin * win + 255) / 256 * 256 / 16);
+        const int total = (g.m_out + 255) / 256, grid = (total + 7) / 8 * 8;
+        const size_t lds = 384 * 128 + 4 * 8192;
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_slab3_expand<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_slab3_expand<0>, dim3(grid), dim3(512), lds, ctx->stream, x, w2, b2, w3, b3, res, y, g, in_blocks);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
     if (mid == 64) return go(k_conv3_expand<256, 8, 2>, 256, 64);
     return go(k_conv3_expand<128, 4, 2>, 128, 128);
 }

@@ -230,15 +230,20 @@ def test_fused_blocks_give_the_same_bits(ctx):
     weights, biases = seeded_parameters(0)
     ctx.cnn_set_weights(weights, biases)
     frames = synth.random_frames(5, 96, 128, seed=21)
-    assert ctx.get_option("cnn_fuse") == 1
+    default = ctx.get_option("cnn_fuse")
+    assert default in (1, 2)
     try:
-        fused, _ = ctx.cnn_forward(frames)
         ctx.set_option("cnn_fuse", 0)
         plain, _ = ctx.cnn_forward(frames)
-    finally:
         ctx.set_option("cnn_fuse", 1)
+        fused, _ = ctx.cnn_forward(frames)
+        ctx.set_option("cnn_fuse", 2)                  # the 56 x 56 stage with the 3x3's input as one slab in LDS (k_slab3_expand)
+        slab, _ = ctx.cnn_forward(frames)
+    finally:
+        ctx.set_option("cnn_fuse", default)
     assert np.isfinite(fused).all() and float(np.abs(fused).max()) > 0
     assert np.array_equal(fused, plain)
+    assert np.array_equal(slab, plain)
 
 
 @pytest.mark.gpu

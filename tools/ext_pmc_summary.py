@@ -20,8 +20,8 @@ def per_dispatch(d, counter):
     return [acc[k] for k in sorted(acc)]
 
 res = {"note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB), separate --pmc passes without tracing domains"}
-f = [x for x in per_dispatch("gpurun_out/ext_pmc_fetch_cnn", "FETCH_SIZE") if any(k in x[0] for k in ("k_conv", "k_cnn", "k_maxpool", "k_avgpool", "k_linear"))]
-w = [x for x in per_dispatch("gpurun_out/ext_pmc_write_cnn", "WRITE_SIZE") if any(k in x[0] for k in ("k_conv", "k_cnn", "k_maxpool", "k_avgpool", "k_linear"))]
+f = [x for x in per_dispatch("gpurun_out/ext_pmc_fetch_cnn", "FETCH_SIZE") if any(k in x[0] for k in ("k_conv", "k_slab", "k_cnn", "k_maxpool", "k_avgpool", "k_linear"))]
+w = [x for x in per_dispatch("gpurun_out/ext_pmc_write_cnn", "WRITE_SIZE") if any(k in x[0] for k in ("k_conv", "k_slab", "k_cnn", "k_maxpool", "k_avgpool", "k_linear"))]
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 50          # launches per forward pass (50 with the fused blocks, 57 layer by layer)
 out_name = sys.argv[2] if len(sys.argv) > 2 else "r04_pmc_extensions.json"
 f, w = f[-per:], w[-per:]

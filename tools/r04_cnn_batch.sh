@@ -13,7 +13,7 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/cnn_kt480/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
-rows = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_conv', 'k_cnn', 'k_stem', 'k_maxpool', 'k_avgpool', 'k_linear'))]
+rows = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_conv', 'k_slab', 'k_cnn', 'k_stem', 'k_maxpool', 'k_avgpool', 'k_linear'))]
 per = len(rows) // 3
 last = rows[-per:]
 tot = 0
