@@ -571,7 +571,15 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
         // bit-identical and slower, 164 us per launch against 142: profiles/r04_experiments.md section 2; the code is in the history, commit 3e8b43a)
         launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
         break;
-    case 160: launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 2, 80, zero_first, mode); break;
+    case 160:
+        // two shapes (ctx->fb_wide160, default 1): a pair as ONE strip of three blocks with the 320-px level's wave mix (119 workgroups of 12 waves,
+        // 58 us per launch) or as two 80-column strips of 14 waves (238 workgroups, 48 us per launch).  The narrow shape finishes a launch sooner
+        // (one clip alone: -25 us); the wide one costs fewer CU-microseconds (119 x 58 against 238 x 48: lanes 91 % instead of 73 % on image
+        // columns, 14 halo columns per pair instead of 28) and that is what counts with clips in flight: +2.4 % frames/s.  The two differ in the
+        // grouping of the solver's window sums (four columns per lane against two): bit-identical on well-posed content, like the 320-px level.
+        if (ctx->fb_wide160) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 160, zero_first, mode);
+        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 2, 80, zero_first, mode);
+        break;
     case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 80, zero_first, mode); break;
     case 40: launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 40, zero_first, mode); break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
