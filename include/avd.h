@@ -270,6 +270,9 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
  * "fb_fold_up" (fast mode, default 1, environment AVD_FB_FOLD_UP; no effect on results): the first launch of the 320-px level
  * resizes the 160-px level's flow itself instead of reading the output of a separate resize launch.
+ * "fb_wide160" (fast mode, default 1, environment AVD_FB_WIDE160): the 160-px level runs a pair as ONE strip of three 64-column blocks
+ * (119 workgroups, fewer CU-microseconds: +2.4 % frames/s with clips in flight) instead of two 80-column strips (238 workgroups, each
+ * launch 10 us shorter: one clip alone finishes ~25 us sooner).  Same guarantee; the two shapes group the solver's window sums differently.
  * "fb_fused" (exact mode only, no effect on results): bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
  * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
  * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM.  "cnn_tiles": tiling of the
