@@ -265,7 +265,8 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * bit.  avd_frame_record.reserved is non-zero for the frame that closes such a pair; avd_get_option "rerun_pairs" counts
  * them for the last drained call.  Stated guarantee of the mode: flow_mean / flow_var within rel 1e-6 and ai_susp within
  * 1e-6 of the oracle (north_star: 1e-4), tests/test_gpu_fbfast.py + the content soak in tests/test_gpu_soak.py; the
- * one family outside it that the soak found is named there.
+ * one family outside it that the soak found is named there (exactly periodic checkerboards shifted by whole pixels: the reference's own
+ * flow moves by more than this library's deviation under one ulp of input noise; fb_mode = exact reproduces them bit for bit).
  * "fb_rerun" (default 1, environment AVD_FB_RERUN): 0 switches the re-run off (A/B, tests).
  * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
  * "fb_fold_up" (fast mode, default 1, environment AVD_FB_FOLD_UP; no effect on results): the first launch of the 320-px level

@@ -9,11 +9,13 @@ flow_mean / flow_var within rel 1e-6 (abs 1e-7) of the oracle and |delta ai_susp
 ai_susp most sensitive to the flow (tex -> infinity: ai_susp = 1 - (1 + mot), so |delta ai_susp| = |delta flow_mean|).
 The CPU experiment behind the flag criterion (tools/experiments/fb_illposed_run.py, 1 440 pairs) is the same generator.
 
-KNOWN RESIDUAL, kept in the soak and reported, not hidden: exactly periodic 2 x 2-cell checkerboards shifted by half a
-period (family "checker", cell size 2).  Their normal equations are well conditioned but the right-hand side is pure
-rounding residue (every window sum cancels exactly in exact arithmetic), so the oracle's own flow moves by pixels under
-one ulp of input noise while neither criterion fires.  fb_mode = exact reproduces them bit for bit (asserted); in the
-default mode they are checked against the oracle's own +-1-ulp sensitivity instead.
+KNOWN RESIDUAL, kept in the soak and reported, not hidden: exactly periodic checkerboards shifted by whole pixels (family
+"checker": cells of 2 .. 32 px).  Their normal equations are well conditioned but where the two frames alias the right-hand
+side is pure rounding residue (every window sum cancels exactly in exact arithmetic), so the oracle's own flow moves by
+1e-4 .. 1e-1 relative under one ulp of input noise while neither criterion fires.  fb_mode = exact reproduces them bit for bit
+(asserted); in the default mode a checkerboard pair outside the tolerance is checked against the oracle's own +-1-ulp
+sensitivity instead (3 of the 60 checkerboard pairs of the 1 440-pair run, profiles/r04_soak_1440.txt; 2 x 2 cells are the
+worst: 5e-2 relative).
 """
 import numpy as np
 import pytest
@@ -22,13 +24,17 @@ pytestmark = pytest.mark.gpu
 
 from tests.content_families import families  # noqa: E402
 
-PER_FAMILY = 12
+import os
+
+PER_FAMILY = int(os.environ.get("AVD_SOAK_PER_FAMILY", "12"))   # 12 x 24 families = 288 pairs; larger one-off runs: profiles/r04_soak_1440.txt
 
 
-def _is_fine_checker(name, seed):
-    if name != "checker":
-        return False
-    return int(np.random.default_rng(seed).choice([2, 4, 8, 16, 32])) == 2
+def _is_checker(name):
+    return name == "checker"
+
+
+def _close(got, want):
+    return abs(float(got) - float(want)) <= max(1e-6 * abs(float(want)), 1e-7)
 
 
 def test_default_mode_on_every_content_family(oracle):
@@ -52,20 +58,23 @@ def test_default_mode_on_every_content_family(oracle):
         m, v = oracle.flow_stats(flow)
         assert xm[2 * k] == m and xv[2 * k] == v, ("exact", name, seed)           # exact mode: bit-identical on every family
         dm = abs(float(fm[2 * k]) - float(m))
-        if _is_fine_checker(name, seed) and dm > 1e-6 * max(abs(m), 0.1):
-            sens = 0.0
+        if _is_checker(name) and not (_close(fm[2 * k], m) and _close(fv[2 * k], v)):
+            sens_m = sens_v = 0.0
             try:
                 for model in (2, 4):
                     lib.avdo_set_model(model)
-                    sens = max(sens, abs(float(oracle.flow_stats(oracle.farneback(a, b))[0]) - float(m)))
+                    mm, vv = oracle.flow_stats(oracle.farneback(a, b))
+                    sens_m = max(sens_m, abs(float(mm) - float(m)))
+                    sens_v = max(sens_v, abs(float(vv) - float(v)))
             finally:
                 lib.avdo_set_model(0)
-            residual.append((seed, dm, sens))
-            assert dm <= 4 * max(sens, 1e-6), (name, seed, dm, sens)
+            dv = abs(float(fv[2 * k]) - float(v))
+            residual.append((seed, dm, sens_m, dv, sens_v))
+            assert dm <= 4 * max(sens_m, 1e-6) and dv <= 4 * max(sens_v, 1e-6), (name, seed, dm, sens_m, dv, sens_v)
             continue
         worst = max(worst, dm)
         assert fm[2 * k] == pytest.approx(m, rel=1e-6, abs=1e-7), (name, seed, float(fm[2 * k]), float(m))
         assert fv[2 * k] == pytest.approx(v, rel=1e-6, abs=1e-7), (name, seed, float(fv[2 * k]), float(v))
         assert dm <= 1e-6 * max(1.0, abs(m)), (name, seed, dm)               # |delta ai_susp| bound at tex -> infinity
     print(f"[soak] {len(jobs)} pairs, {len(fam)} families: max |delta flow_mean| = {worst:.3g}; pairs re-run in the call "
-          f"(incl. the in-between pairs): {rerun_total}; fine-checkerboard residual (seed, |delta mean|, oracle +-1 ulp): {residual}")
+          f"(incl. the in-between pairs): {rerun_total}; checkerboard residual (seed, |delta mean|, oracle +-1 ulp, |delta var|, oracle +-1 ulp): {residual}")
