@@ -518,51 +518,64 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // one tap (64 x 64 bf16 = 8 KB, one LDS-DMA instruction per wave) per step, ring of four, 16 MFMAs per wave between barriers.
 // Same K order (tap, then channel block) as the gathering kernels: bit-identical.  The expanding layer follows as in
 // k_conv3_expand (resident W3; it is requested after the last tap, when the slab is dead).
-template <int DUMMY>
+// MID = 64 (56 x 56: 256-pixel tiles, a whole tap of W2 per step, W3 resident) or 128 (28 x 28: 128-pixel tiles, slab = 192 pixels x 4 channel
+// blocks -- again 48 contiguous KiB --, W2 streams in half stages of 32 input channels = 8 KiB like the gathering kernel, W3 in two alternating
+// chunk buffers).
+template <int MID>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slab3_expand(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W2,
                                                      const float* __restrict__ bias2, const uint16_t* __restrict__ W3,
                                                      const float* __restrict__ bias3, const uint16_t* __restrict__ R,
                                                      uint16_t* __restrict__ Y, ConvGeom g, int in_blocks)
 {
-    constexpr int BM = 256, TI = 2, TJ = 4, BN = 64, KS2 = 2, NCH = 4;
-    constexpr int NSLAB = 384, SLAB = NSLAB * 128, TAPB = BN * 64 * 2, LDS = SLAB + 4 * TAPB;      // 48 KiB + 4 x 8 KiB = 80 KiB
-    constexpr int A2 = BM * BN * 2, B2 = BN * BN * 2, W3BASE = 0, A2BASE = NCH * B2;                // after the taps: W3 | mid tile | bias3
-    static_assert(A2BASE + A2 + NCH * BN * 4 <= LDS, "LDS plan of the expanding layer");
+    static_assert(MID == 64 || MID == 128, "the two early stages");
+    constexpr int BN = MID, WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, TI = 2, TJ = 4, BM = WAVES_M * TI * 16;   // 256 x 64 or 128 x 128
+    constexpr int CPB = MID / 32, KS2 = CPB, NCH = 4;       // channel blocks of the input = k steps of the expanding layer
+    constexpr int HALO = MID == 64 ? 64 : 32;               // pixels in front of m0 (>= W + 1, whole pixel blocks)
+    constexpr int NSLAB = BM + 2 * HALO, SLAB = NSLAB * CPB * 64;                 // 384 x 128 B = 192 x 256 B = 48 KiB
+    constexpr int KPS = MID == 64 ? 2 : 1;                  // k blocks of W2 per step (a whole tap at 64 channels, a quarter tap at 128)
+    constexpr int STEPB = BN * 64 * KPS, NSTEP = 9 * CPB / KPS, LDS = SLAB + 4 * STEPB;   // 8 KiB per step, ring of four: 80 KiB
+    constexpr int A2 = BM * BN * 2, B2 = BN * BN * 2;
+    constexpr bool RESIDENT = NCH * B2 + A2 + NCH * BN * 4 <= LDS;               // W3 | mid tile | bias3 (mid 64); else two chunk buffers
+    constexpr int A2BASE = RESIDENT ? NCH * B2 : B2, BIAS3 = RESIDENT ? A2BASE + A2 : 2 * B2;
+    static_assert(SLAB == 49152 && STEPB == 8192 && BIAS3 + NCH * BN * 4 <= LDS && A2BASE + A2 <= LDS, "LDS plan");
+    constexpr int NBLK = (BN / 16) * KS2;                   // KiB blocks of one W3 chunk
+    constexpr int NRES = TI * TJ / 2;
     extern __shared__ __align__(16) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave;                                     // eight waves along the pixels, one column tile
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int total = (g.m_out + BM - 1) / BM;
     const int per = (gridDim.x + 7) >> 3;
     const int lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (lid >= total) return;
     const int m0 = lid * BM;
+    static_assert(NCH * BN <= 512, "one bias3 element per thread");
     float b3v = threadIdx.x < NCH * BN ? bias3[threadIdx.x] : 0.f;
     asm volatile("" : "+v"(b3v));                            // arrived before the queue fills (k_conv3_expand)
     const int chunk = lane >> 4, r16 = lane & 15;
     const char* xb = reinterpret_cast<const char*>(X);
 
-    // ---- the slab: pixel blocks (m0 >> 4) - 4 .. + 23, two channel blocks each; blocks outside the activation come from the zero page
-    // (their pixels are masked in every tap: they only must not fault)
-    const int blk0 = (m0 >> 4) - 4;
+    // ---- the slab: NSLAB / 16 pixel blocks from (m0 - HALO) >> 4 on, CPB channel blocks each = 48 KiB blocks, six per wave; blocks outside
+    // the activation come from the zero page (their pixels are masked in every tap: they only must not fault)
+    const int blk0 = (m0 - HALO) >> 4;
 #pragma unroll
     for (int j0 = 0; j0 < 48; j0 += 8) {
-        const int j = j0 + wave, pb = blk0 + (j >> 1);
+        const int j = j0 + wave, pb = blk0 + j / CPB;
         const bool ok = pb >= 0 && pb < in_blocks;          // wave-uniform
-        const char* src = ok ? xb + kZeroPage * 2 + ((size_t)pb * 2 + (j & 1)) * 1024 + lane * 16 : xb + lane * 16;
+        const char* src = ok ? xb + kZeroPage * 2 + ((size_t)pb * CPB + j % CPB) * 1024 + lane * 16 : xb + lane * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
     }
-    // one tap of W2 = k blocks 2 t, 2 t + 1 of the four weight-row blocks: eight KiB blocks, one per wave
-    auto issue_tap = [&](int t) __attribute__((always_inline)) {
-        const int rb = wave >> 1, kbl = wave & 1;
-        const char* src = reinterpret_cast<const char*>(W2) + ((size_t)(rb * 18 + 2 * t + kbl)) * 1024 + lane * 16;
+    // one step of W2 = KPS k blocks of all BN weight rows: eight KiB blocks, one per wave (k block of step s: s * KPS ..; K = 9 MID)
+    auto issue_w2 = [&](int st) __attribute__((always_inline)) {
+        const int rb = MID == 64 ? wave >> 1 : wave, kbl = MID == 64 ? wave & 1 : 0;
+        const char* src = reinterpret_cast<const char*>(W2) + ((size_t)(rb * (9 * CPB) + st * KPS + kbl)) * 1024 + lane * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + SLAB + (t & 3) * TAPB + kbl * (BN * 64) + rb * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds + SLAB + (st & 3) * STEPB + kbl * (BN * 64) + rb * 1024), 16, 0, 0);
     };
-    issue_tap(0); issue_tap(1); issue_tap(2);
+    issue_w2(0); issue_w2(1); issue_w2(2);
 
-    // per-lane tap masks of this wave's two row tiles, and the slab row of tap (0, 0) - i.e. shift 0 - of each
+    // per-lane tap masks of this wave's two row tiles, and the slab row of shift 0 of each
     unsigned tapmask[TI];
     int qbase[TI];
     const int hw = g.hout * g.wout;
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (valid && (unsigned)yi < (unsigned)g.hin && (unsigned)xi < (unsigned)g.win) mk |= 1u << t;
         }
         tapmask[i] = mk;
-        qbase[i] = 64 + pl;
+        qbase[i] = HALO + pl;
     }
     f32x4 acc[TI][TJ];
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -588,73 +601,85 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    auto b_row = [&](int j, int rho) __attribute__((always_inline)) { return (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3); };
+    auto b_row = [&](int j, int rho) __attribute__((always_inline)) { return wn * 64 + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3); };
     const unsigned loff = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ swz((lane >> 2) & 3)) << 4));
     constexpr int cblocks = (NCH * BN) >> 5;
-    uint4 rv[2][TI][TJ / 2];
-    const unsigned obase = (unsigned)(kZeroPage * 2) + (unsigned)(((m0 >> 4) + wm * TI) * cblocks) * 1024u + loff;
+    constexpr bool PF = RESIDENT;                            // residuals one chunk ahead (two register sets) only where the registers allow
+    uint4 rv[PF ? 2 : 1][TI][TJ / 2];
+    const unsigned obase = (unsigned)(kZeroPage * 2) + (unsigned)(((m0 >> 4) + wm * TI) * cblocks + wn * 2) * 1024u + loff;
     auto out_off = [&](int c, int i, int jp) __attribute__((always_inline)) { return obase + (unsigned)((i * cblocks + c * (BN >> 5) + jp) * 1024); };
     auto load_res = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TI; i++)
 #pragma unroll
             for (int jp = 0; jp < TJ / 2; jp++)
-                rv[c & 1][i][jp] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(R) + out_off(c, i, jp));
+                rv[PF ? (c & 1) : 0][i][jp] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(R) + out_off(c, i, jp));
     };
 
-    // ---- 1. the nine taps
+    // ---- 1. the nine taps (K order: tap, then channel block -- the gathering kernels' order)
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
+    for (int st = 0; st < NSTEP; st++) {
         __builtin_amdgcn_sched_barrier(0);
-        if (t < 7) AVD_WAIT_VMC(2);                          // taps t + 1, t + 2 may still be in flight (the slab is older than tap 0)
-        else if (t == 7) AVD_WAIT_VMC(1);
+        if (st < NSTEP - 2) AVD_WAIT_VMC(2);                 // steps st + 1, st + 2 may still be in flight (the slab is older than step 0)
+        else if (st == NSTEP - 2) AVD_WAIT_VMC(1);
         else AVD_WAIT_VMC(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 3 < 9) issue_tap(t + 3);
-        else if (t == 8) load_res(0);                        // the first residuals, a whole step + the mid tile's epilogue ahead
+        if (st + 3 < NSTEP) issue_w2(st + 3);
+        else if (PF && st == NSTEP - 1) load_res(0);         // the first residuals, a whole step + the mid tile's epilogue ahead
         __builtin_amdgcn_sched_barrier(0);
+        const int t = st * KPS / CPB, cb0 = st * KPS % CPB;  // tap and first channel block of the step
         const int shift = (t / 3 - 1) * g.win + (t % 3 - 1);
-        const char* st = lds + SLAB + (t & 3) * TAPB;
-        bf16x8 a[TI][2], b[TJ][2];
+        const char* sb = lds + SLAB + (st & 3) * STEPB;
+        bf16x8 a[TI][KPS], b[TJ][KPS];
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
+        for (int kb = 0; kb < KPS; kb++) {
 #pragma unroll
-            for (int j = 0; j < TJ; j++) b[j][kb] = frag(st + kb * (BN * 64), b_row(j, r16), chunk);
+            for (int j = 0; j < TJ; j++) b[j][kb] = frag(sb + kb * (BN * 64), b_row(j, r16), chunk);
 #pragma unroll
             for (int i = 0; i < TI; i++) {
                 const int q = qbase[i] + shift;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + (q >> 4) * 2048 + kb * 1024 + (q & 15) * 64 + ((chunk ^ swz(((q & 15) >> 2) & 3)) << 4));
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + (q >> 4) * (CPB * 1024) + (cb0 + kb) * 1024 + (q & 15) * 64 +
+                                                                  ((chunk ^ swz(((q & 15) >> 2) & 3)) << 4));
                 a[i][kb] = ((tapmask[i] >> t) & 1u) ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++)
+        for (int kb = 0; kb < KPS; kb++)
 #pragma unroll
             for (int i = 0; i < TI; i++)
 #pragma unroll
                 for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kb], a[i][kb], acc[i][j], 0, 0, 0);
     }
 
-    // ---- 2. W3 into the dead slab, the mid tile -> LDS -> this wave's fragments
+    // ---- 2. W3 (its first chunk) into the dead slab, the mid tile -> LDS -> this wave's fragments
     char* const a2 = lds + A2BASE;
-    float* const lbias3 = reinterpret_cast<float*>(lds + A2BASE + A2);
+    float* const lbias3 = reinterpret_cast<float*>(lds + BIAS3);
+    auto issue_w3 = [&](int c) __attribute__((always_inline)) {
+        char* buf = lds + (RESIDENT ? c : (c & 1)) * B2;
+        const char* src = reinterpret_cast<const char*>(W3) + (size_t)c * NBLK * 1024 + lane * 16;
+#pragma unroll
+        for (int t0 = 0; t0 < NBLK; t0 += 8) {
+            const int t = t0 + wave, rbl = t / KS2, kb = t % KS2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + t * 1024),
+                                             (__attribute__((address_space(3))) void*)(buf + kb * (BN * 64) + rbl * 1024), 16, 0, 0);
+        }
+    };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // every wave has read its last fragments
     __builtin_amdgcn_sched_barrier(0);
     f32x4 b2lo[TJ / 2], b2hi[TJ / 2];
 #pragma unroll
     for (int jp = 0; jp < TJ / 2; jp++) {
-        const float* pb = bias2 + jp * 32 + (lane >> 4) * 8;
+        const float* pb = bias2 + wn * 64 + jp * 32 + (lane >> 4) * 8;
         b2lo[jp] = *reinterpret_cast<const f32x4*>(pb);
         b2hi[jp] = *reinterpret_cast<const f32x4*>(pb + 4);
     }
+    if (RESIDENT) {
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {                          // W3: four chunks of 64 rows x 64 k = 8 KiB blocks each, one per wave
-        const int rbl = wave / KS2, kb = wave % KS2;
-        const char* src = reinterpret_cast<const char*>(W3) + ((size_t)c * 8 + wave) * 1024 + lane * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + W3BASE + c * B2 + kb * (BN * 64) + rbl * 1024), 16, 0, 0);
+        for (int c = 0; c < NCH; c++) issue_w3(c);
+    } else {
+        issue_w3(0);
     }
     if (threadIdx.x < NCH * BN) lbias3[threadIdx.x] = b3v;
 #pragma unroll
@@ -668,29 +693,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             uint4 pk;
             pk.x = pack_bf16x2(lo[0], lo[1]); pk.y = pack_bf16x2(lo[2], lo[3]);
             pk.z = pack_bf16x2(hi[0], hi[1]); pk.w = pack_bf16x2(hi[2], hi[3]);
-            *reinterpret_cast<uint4*>(a2 + jp * (BM * 64) + (wm * TI + i) * 1024 + loff) = pk;
+            *reinterpret_cast<uint4*>(a2 + (wn * 2 + jp) * (BM * 64) + (wm * TI + i) * 1024 + loff) = pk;
         }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                            // W3 and the mid tile are complete for everyone
+    __builtin_amdgcn_s_barrier();                            // W3 (its first chunk) and the mid tile are complete for everyone
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 am[KS2][TI];
 #pragma unroll
     for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
         for (int i = 0; i < TI; i++) am[ks][i] = frag(a2 + ks * (BM * 64), (wm * TI + i) * 16 + r16, chunk);
+    if (!RESIDENT) {                                         // the second W3 buffer takes over the mid tile's LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
-    // ---- 3. the expanding 1x1 (k_conv3_expand's resident form: no barrier in the loop)
+    // ---- 3. the expanding 1x1 (k_conv3_expand's chunk loop)
     static_assert(NCH % 2 == 0, "unrolled by two");
 #pragma unroll 1
     for (int c2 = 0; c2 < NCH; c2 += 2)
 #pragma unroll
     for (int cc = 0; cc < 2; cc++) {
         const int c = c2 + cc;
-        if (c + 1 < NCH) load_res(c + 1);
+        if (!PF) load_res(c);
+        if (!RESIDENT && c + 1 < NCH) issue_w3(c + 1);
+        if (PF && c + 1 < NCH) load_res(c + 1);
         __builtin_amdgcn_sched_barrier(0);
         zero_acc();
-        const char* buf = lds + W3BASE + c * B2;
+        const char* buf = lds + (RESIDENT ? c : (c & 1)) * B2;
 #pragma unroll
         for (int ks = 0; ks < KS2; ks++) {
             bf16x8 b[TJ];
@@ -705,10 +737,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = 0; i < TI; i++)
 #pragma unroll
             for (int jp = 0; jp < TJ / 2; jp++) {
-                const float* pb = lbias3 + c * BN + jp * 32 + (lane >> 4) * 8;
+                const float* pb = lbias3 + c * BN + wn * 64 + jp * 32 + (lane >> 4) * 8;
                 f32x4 lo = acc[i][2 * jp] + *reinterpret_cast<const f32x4*>(pb);
                 f32x4 hi = acc[i][2 * jp + 1] + *reinterpret_cast<const f32x4*>(pb + 4);
-                const uint4 r = rv[c & 1][i][jp];
+                const uint4 r = rv[PF ? (c & 1) : 0][i][jp];
                 lo[0] += bf16_to_f32(r.x & 0xFFFF); lo[1] += bf16_to_f32(r.x >> 16);
                 lo[2] += bf16_to_f32(r.y & 0xFFFF); lo[3] += bf16_to_f32(r.y >> 16);
                 hi[0] += bf16_to_f32(r.z & 0xFFFF); hi[1] += bf16_to_f32(r.z >> 16);
@@ -721,6 +753,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Y) + out_off(c, i, jp)) = pk;
             }
         __builtin_amdgcn_sched_barrier(0);
+        if (!RESIDENT && c + 1 < NCH) {
+            AVD_WAIT_VMC(NRES);                              // younger than DMA(c + 1): the stores of chunk c
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // the next chunk has landed for every wave; everyone is done reading this one
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -941,15 +979,20 @@ int launch_conv3_expand(avd_ctx* ctx, const uint16_t* x, const uint16_t* w2, con
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
-    if (mid == 64 && stride == 1 && ctx->cnn_fuse == 2) {
+    if (stride == 1 && ctx->cnn_fuse == 2) {
         // the 3x3's input as one slab in LDS (k_slab3_expand); the blocks of the input activation that exist: its rows are padded to 256
         const int in_blocks = (int)(((size_t)n * hin * win + 255) / 256 * 256 / 16);
-        const int total = (g.m_out + 255) / 256, grid = (total + 7) / 8 * 8;
-        const size_t lds = 384 * 128 + 4 * 8192;
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_slab3_expand<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_slab3_expand<0>, dim3(grid), dim3(512), lds, ctx->stream, x, w2, b2, w3, b3, res, y, g, in_blocks);
-        HIP_TRY(ctx, hipGetLastError());
-        return 0;
+        const int bm = mid == 64 ? 256 : 128;
+        if (win + 1 > (mid == 64 ? 64 : 32)) { ctx->err = "conv3_expand: the slab's halo is sized for 56 x 56 (mid 64) and 28 x 28 (mid 128)"; return AVD_ERR_ARG; }
+        const int total = (g.m_out + bm - 1) / bm, grid = (total + 7) / 8 * 8;
+        const size_t lds = 49152 + 4 * 8192;
+        auto slab = [&](auto kern) -> int {
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, x, w2, b2, w3, b3, res, y, g, in_blocks);
+            HIP_TRY(ctx, hipGetLastError());
+            return 0;
+        };
+        return mid == 64 ? slab(k_slab3_expand<64>) : slab(k_slab3_expand<128>);
     }
     if (mid == 64) return go(k_conv3_expand<256, 8, 2>, 256, 64);
     return go(k_conv3_expand<128, 4, 2>, 128, 128);

@@ -964,7 +964,7 @@ def main():
             out["mfma_cnn_forward"] = {
                 "kernel": "k_conv_bf16 + k_conv3_expand (ResNet-50-style forward: every convolution one implicit GEMM, the activation operand gathered by "
                           "LDS-DMA from blocked + swizzled bf16 activations, bias / residual / ReLU fused; in the 56x56 and 28x28 stages a block's 3x3 and its "
-                          "expanding 1x1 are ONE launch with the mid activation in LDS, at 56x56 with the 3x3's input as one slab in LDS (k_slab3_expand); the 7x7 stem gathers pixel pairs from a zero-bordered input image) + input conversion, max / average pooling, linear",
+                          "expanding 1x1 are ONE launch with the mid activation in LDS, in the stride-1 blocks with the 3x3's input as one slab in LDS (k_slab3_expand); the 7x7 stem gathers pixel pairs from a zero-bordered input image) + input conversion, max / average pooling, linear",
                 "extension": "no reference counterpart (the reference has no learned model); seeded random weights; not part of value / ai_score",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                 "frames_per_forward": cnn["frames"], "gmac_per_frame": round(cnn["macs_per_frame"] / 1e9, 3),

@@ -280,7 +280,7 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * CNN extension's convolutions, 0 = by layer shape (default), 1 = 256-pixel tiles everywhere, 2 = 128 x 128 tiles wherever the
  * channel count allows (the accumulation order of an output does not depend on the tiling: results are bit-identical).
  * "cnn_fuse" (default 2): a bottleneck block's 3x3 and its expanding 1x1 run as ONE launch in the 56x56 and 28x28 stages
- * (the mid activation stays in LDS; bit-identical to the two layers); 2 = at 56x56 the 3x3 also reads its nine taps from one
+ * (the mid activation stays in LDS; bit-identical to the two layers); 2 = in their stride-1 blocks the 3x3 also reads its nine taps from one
  * copy of its input in LDS instead of gathering them tap by tap; 1 = gathering form everywhere; 0 = layer by layer.  "cnn_chunk" (default 128, 1 ... 1024):
  * frames per forward pass of avd_cnn_forward (activation scratch: 4 x 1.6 MB per frame).
  * avd_get_option returns the value an option has now (environment defaults included) and the read-only "rerun_pairs". */
