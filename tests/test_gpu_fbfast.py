@@ -212,6 +212,38 @@ def test_folded_launches_are_bit_identical(oracle):
             c.set_option("fb_fold_up", 5)
 
 
+def test_level_shapes_are_bit_identical(oracle):
+    """The two shapes of the 160-px level -- one three-block strip per pair (fb_wide160, the default) or two strips -- differ only in
+    which lanes hold which columns and in the grouping of the solver's window sums (four columns per lane or two).  On well-posed
+    content the flow of EVERY level is bit-identical; on the hard set it is with the re-run on (the ill-posed pairs are re-run exactly
+    in either shape)."""
+    import avd_hip
+    sets = [_smalls(oracle, synth.make_clip(6, 360, 640, seed=22, dup_every=4)), synth.random_frames(8, 320, 320, seed=6)[..., 1].copy(),
+            _hard_frames()]
+
+    def levels(c, n):
+        return [c.debug_fetch(f"flow{k}", (n - 1, 2, 320 >> k, 320 >> k), np.float32) for k in range(4)]
+
+    with avd_hip.Context(0) as c:
+        c.set_option("fb_mode", 1)
+        assert c.get_option("fb_wide160") == 1
+        for si, frames in enumerate(sets):
+            hard = si == 2
+            c.set_option("fb_rerun", 1 if hard else 0)
+            c.set_option("fb_wide160", 0)
+            fm0, fv0, flow0 = c.farneback_pairs(frames, want_flow=True)
+            lvl0 = levels(c, len(frames))
+            n0 = c.get_option("rerun_pairs")
+            c.set_option("fb_wide160", 1)
+            fm1, fv1, flow1 = c.farneback_pairs(frames, want_flow=True)
+            assert c.get_option("rerun_pairs") == n0
+            assert np.array_equal(flow0.view(np.uint32), flow1.view(np.uint32)), si
+            assert np.array_equal(fm0, fm1) and np.array_equal(fv0, fv1), si
+            if not hard:
+                for k, lv in enumerate(levels(c, len(frames))):
+                    assert np.array_equal(lv.view(np.uint32), lvl0[k].view(np.uint32)), (si, k)
+
+
 @pytest.mark.parametrize("n,h,w,dur", [(12, 360, 640, 6.0), (6, 720, 1280, 3.0), (5, 1080, 1920, 2.5), (3, 2160, 3840, 1.5)])
 def test_ai_susp_within_tolerance_every_geometry(ctxs, oracle, n, h, w, dur):
     """End to end (video.py:36-83): timeline / summary of both modes against the oracle chain on the BASELINE geometries."""
