@@ -15,6 +15,7 @@
  *     i = 4  (|g11 h2| + |g12 h1| + |g22 h1| + |g12 h2|) / (det + 1e-3) / level width   cancellation in the numerators
  *     i = 6  max |f(x+1) - f(x)| inside a solver lane's four columns
  *     i = 5  fraction of pixels with max(|fx|, |fy|) > width / 8
+ *     i = 7  max |new flow - incoming flow| of an iteration (px of the level)
  */
 #include <stdio.h>
 #include "fb_tolerance_exp.c"
@@ -87,6 +88,13 @@ static void blur_ind(const float* R0, const float* R1, float* flow_, float* matM
                 const double r = fmax(fabs((double)f[2] - f[0]), fabs((double)f[3] - f[1]));
                 if (r > g_ind[6]) g_ind[6] = r;
             }
+    }
+    if (g_ind) {
+        /* i = 7: the iteration's UPDATE, max |new flow - incoming flow| (px of this level) */
+        for (int64_t t = 0; t < (int64_t)w * h * 2; t++) {
+            const double u = fabs((double)newflow[t] - (double)flow_[t]);
+            if (u > g_ind[7]) g_ind[7] = u;
+        }
     }
     memcpy(flow_, newflow, sizeof(float) * (size_t)w * h * 2);
     if (update_matrices) avdo_update_matrices(R0, R1, flow_, matM, h, w, 0, h);
