@@ -214,7 +214,7 @@ def compact_line(full, details_path=None):
     line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
     line["config"] = pick(full["config"], ("workload", "frames_per_clip", "height", "width", "clips_per_step", "clips_in_flight_per_gpu",
-                                           "fb_mode", "sec_per_video", "sec_per_video_resident", "sec_per_video_nv12", "parallelism"))
+                                           "fb_mode", "fb_wide160", "sec_per_video", "sec_per_video_resident", "sec_per_video_nv12", "parallelism"))
     line["repeats"] = pick(full.get("repeats"), ("n", "statistic", "value_min", "value_max"))
     r = full["roofline"]
     line["roofline"] = pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_from_profiles",
@@ -879,6 +879,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: 1080p30 60 s clip, 2 fps sampling, one clip per GPU per step",
                        "frames_per_clip": n, "height": h, "width": w, "clips_per_step": world, "clips_in_flight_per_gpu": m,
                        "fb_mode": fb_mode_used,
+                       "fb_wide160": int(ctxs[0].get_option("fb_wide160")),      # 1 = the 160-px level as one strip per pair (throughput shape, the default)
                        "input_copies_in_hbm": m,
                        "sec_per_video": round((host_lat_ms if host_lat_ms is not None else latency_ms) / 1e3, 6),
                        "sec_per_video_note": ("one clip alone, from decoded frames in pinned host memory to the fused result "
