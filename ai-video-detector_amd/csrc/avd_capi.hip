@@ -393,6 +393,7 @@ static int impl_create(int device_id, avd_ctx** out)
         if (const char* e = std::getenv("AVD_FB_FUSED")) ctx->fb_fused = (int)std::strtol(e, nullptr, 0) & 0xF;
         if (const char* e = std::getenv("AVD_FB_FOLD_UP")) ctx->fb_fold_up = std::atoi(e) & 15;
         if (const char* e = std::getenv("AVD_FB_WIDE160")) ctx->fb_wide160 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVD_FB_FOLD_BLUR")) ctx->fb_fold_blur = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
         if (const char* e = std::getenv("AVD_FB_RERUN")) ctx->fb_rerun = std::atoi(e) != 0;
         build_fb_consts(ctx->fbc);
@@ -835,6 +836,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 15; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value != 0; return AVD_OK; }
+    if (std::strcmp(name, "fb_fold_blur") == 0) { ctx->fb_fold_blur = value != 0; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
     if (std::strcmp(name, "cnn_fuse") == 0) { ctx->cnn_fuse = value < 0 ? 0 : (value > 2 ? 2 : value); return AVD_OK; }
     if (std::strcmp(name, "cnn_chunk") == 0) {
@@ -856,6 +858,7 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_fold_up") == 0) { *value = ctx->fb_fold_up; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { *value = ctx->fb_wide160; return AVD_OK; }
+    if (std::strcmp(name, "fb_fold_blur") == 0) { *value = ctx->fb_fold_blur; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { *value = ctx->cnn_tiles; return AVD_OK; }
     if (std::strcmp(name, "cnn_fuse") == 0) { *value = ctx->cnn_fuse; return AVD_OK; }
     if (std::strcmp(name, "cnn_chunk") == 0) { *value = ctx->cnn_chunk; return AVD_OK; }

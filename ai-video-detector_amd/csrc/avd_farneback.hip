@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
     if (b < n2) { pyramid_body<2>(lds, b, small, C, I2); return; }
     b -= n2;
     if (b < n1) { pyramid_body<1>(lds, b, small, C, I1); return; }
-    pyramid_body<0>(lds, b - n1, small, C, I0);
+    if (I0) pyramid_body<0>(lds, b - n1, small, C, I0);     // null: the polynomial expansion forms the 320-px scale's 3 x 3 blur itself (the grid ends before)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
 // neighbour's as ten consecutive floats).  The workgroup's output is ONE contiguous span of 1600 floats: it is staged in
 // LDS and stored as 16-byte pieces (a lane's own five floats are 20 bytes apart from its neighbour's).
 // ---------------------------------------------------------------------------------------
-struct PolyPtrs { const float* I[AVD_FB_LEVELS]; float* R[AVD_FB_LEVELS]; };
+struct PolyPtrs { const float* I[AVD_FB_LEVELS]; float* R[AVD_FB_LEVELS]; const uint8_t* small; };   // small != null: the 320-px scale is blurred here
 
 constexpr int kPolyRows = 16;                            // image rows per workgroup of the full-resolution scale
 
@@ -185,11 +185,38 @@ constexpr int kPolyRows = 16;                            // image rows per workg
 // eleven, 18 / 8 loads per row with the halo), the two LDS buffers alternate, so a row costs ONE workgroup barrier, and the
 // coalesced 16-byte stores of row i - 1 are issued while row i is in its horizontal pass.  Same arithmetic per pixel as
 // the one-row form below (which still serves the three small scales): bit-identical.
-__device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, float* __restrict__ out, int y0, const FbConsts* __restrict__ C,
-                                                float (*rowb)[3][S + 80], float (*outb)[S * 5])
+// FOLD: the scale's input is not the pyramid kernel's blurred float image but the 320 x 320 gray bytes themselves; the 3 x 3 Gaussian of
+// pyramid_body<0> (BORDER_REFLECT_101, the same two float passes in the same operation order: bit-identical) is formed on the way into the
+// register window -- one 4-byte load per new row instead of one float load, a rolling window of three horizontally filtered rows.  Saves the
+// 320-px tiles of the pyramid kernel and 49 MB written + read per 120 frames.
+template <bool FOLD>
+__device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, const uint8_t* __restrict__ small, float* __restrict__ out, int y0,
+                                                const FbConsts* __restrict__ C, float (*rowb)[3][S + 80], float (*outb)[S * 5])
 {
     constexpr int w = S, h = S;
     const int x = threadIdx.x;
+    // FOLD: bytes x - 1, x, x + 1 of a row (reflected at the image edge) out of ONE 4-byte load at xs = clamp(x - 1, 0, w - 4)
+    const int xs = x - 1 < 0 ? 0 : (x - 1 > w - 4 ? w - 4 : x - 1);
+    const int shl = ((x == 0 ? 1 : x - 1) - xs) * 8, shc = (x - xs) * 8, shr = ((x == w - 1 ? w - 2 : x + 1) - xs) * 8;
+    const float kx0 = C->gk[0][0], kx1 = C->gk[0][1], kx2 = C->gk[0][2];
+    struct __attribute__((packed, aligned(1))) U4 { unsigned v; };
+    auto hb = [&](int srow) __attribute__((always_inline)) {               // horizontally filtered value of source row reflect101(srow) at this column
+        const int sr = srow < 0 ? -srow : (srow > h - 1 ? 2 * (h - 1) - srow : srow);
+        const unsigned wd = reinterpret_cast<const U4*>(small + sr * w + xs)->v;
+        const float l = (float)((wd >> shl) & 0xFFu), c = (float)((wd >> shc) & 0xFFu), r = (float)((wd >> shr) & 0xFFu);
+        return __builtin_fmaf(c, kx1, (l + r) * kx0);
+    };
+    float hm = 0.f, h0 = 0.f, hp = 0.f;                      // filtered rows rcur - 1, rcur, rcur + 1
+    int rcur = -1000;
+    auto blurred = [&](int r) __attribute__((always_inline)) {             // value of the blurred image at (r, x), r clamped by the caller; rows only move down
+        if (r != rcur) {                                     // workgroup-uniform
+            if (r == rcur + 1) { hm = h0; h0 = hp; hp = hb(r + 1); }
+            else { hm = hb(r - 1); h0 = hb(r); hp = hb(r + 1); }
+            rcur = r;
+        }
+        return __builtin_fmaf(hp + hm, kx2, __builtin_fmaf(h0, kx1, 0.f));
+    };
+    auto pixel = [&](int r) __attribute__((always_inline)) { return FOLD ? blurred(r) : img[r * w + x]; };
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     // the kernel is VALU-bound (profiles/r03_experiments.md): the taps live in registers for all rows of the workgroup, as
@@ -202,11 +229,11 @@ __device__ __forceinline__ void polyexp_rows320(const float* __restrict__ img, f
     const double ig11 = C->ig11, ig03 = C->ig03, ig33 = C->ig33, ig55 = C->ig55;
     float win[11 + kPolyRows];                           // rows y0 - 5 .. y0 + kPolyRows + 4 of this column (clamped: replicate border)
 #pragma unroll
-    for (int q = 0; q < 10; q++) win[q] = img[min(max(y0 - 5 + q, 0), h - 1) * w + x];
+    for (int q = 0; q < 10; q++) win[q] = pixel(min(max(y0 - 5 + q, 0), h - 1));
 #pragma unroll
     for (int i = 0; i < kPolyRows; i++) {                // fully unrolled: the window is a static slice win[i .. i + 10]
         const int y = y0 + i, par = i & 1;
-        win[i + 10] = img[min(y + 5, h - 1) * w + x];
+        win[i + 10] = pixel(min(y + 5, h - 1));
         {
             f2 t02 = f2{win[i + 5] * g[0], 0.f};
             float t1 = 0.f;
@@ -287,7 +314,8 @@ __global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const Fb
             const int per = cnt0 >> 3, lid = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
             if (lid >= wgs0) return;
             const int f = lid / (S / kPolyRows), y0 = (lid - f * (S / kPolyRows)) * kPolyRows;
-            polyexp_rows320(P.I[0] + (int64_t)f * S * S, P.R[0] + (int64_t)f * S * S * 5, y0, C, rowb, outbb);
+            if (P.small) polyexp_rows320<true>(nullptr, P.small + (int64_t)f * S * S, P.R[0] + (int64_t)f * S * S * 5, y0, C, rowb, outbb);
+            else polyexp_rows320<false>(P.I[0] + (int64_t)f * S * S, nullptr, P.R[0] + (int64_t)f * S * S * 5, y0, C, rowb, outbb);
             return;
         }
     }
@@ -1029,10 +1057,15 @@ inline void launch1d(void (*k)(A...), int64_t items, int block, hipStream_t s, A
 void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int n)
 {
     const FbConsts* C = (const FbConsts*)ctx->d_fbc;
-    const int wgs = n * (PyrGeo<0>::TILES + PyrGeo<1>::TILES + PyrGeo<2>::TILES + PyrGeo<3>::TILES);
+    // ctx->fb_fold_blur (default 1): the 320-px scale's 3 x 3 blur is formed inside the polynomial expansion; the pyramid kernel then has no
+    // 320-px tiles and pyr[0] is not written (avd_debug_copy "pyr0" is meaningful with the option off only)
+    const bool fold = ctx->fb_fold_blur != 0;
+    const int wgs = n * ((fold ? 0 : PyrGeo<0>::TILES) + PyrGeo<1>::TILES + PyrGeo<2>::TILES + PyrGeo<3>::TILES);
     kmark(ctx, AVD_K_PYRAMID);
-    hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, g.pyr_w[0], g.pyr_w[1], g.pyr_w[2], g.pyr_w[3], g.flags);
+    hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, fold ? (float*)nullptr : g.pyr_w[0], g.pyr_w[1], g.pyr_w[2],
+                       g.pyr_w[3], g.flags);
     PolyPtrs P;
+    P.small = fold ? d_small : nullptr;
     int grid = ((n * (S / kPolyRows) + 7) >> 3) << 3;      // the 320-px scale: kPolyRows rows per workgroup
     for (int k = 0; k < AVD_FB_LEVELS; k++) {
         P.I[k] = g.pyr[k]; P.R[k] = g.poly[k];

@@ -271,6 +271,9 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
  * "fb_fold_up" (fast mode, default 1, environment AVD_FB_FOLD_UP; no effect on results): the first launch of the 320-px level
  * resizes the 160-px level's flow itself instead of reading the output of a separate resize launch.
+ * "fb_fold_blur" (default 1, environment AVD_FB_FOLD_BLUR; no effect on results): the 3 x 3 Gaussian of the 320-px pyramid scale is formed inside
+ * the polynomial expansion (same two float passes, same operation order) instead of being written by the pyramid kernel and read back;
+ * avd_debug_copy "pyr0" is meaningful with the option off only.
  * "fb_wide160" (fast mode, default 1, environment AVD_FB_WIDE160): the 160-px level runs a pair as ONE strip of three 64-column blocks
  * (119 workgroups, fewer CU-microseconds: +2.4 % frames/s with clips in flight) instead of two 80-column strips (238 workgroups, each
  * launch 10 us shorter: one clip alone finishes ~25 us sooner).  Same guarantee; the two shapes group the solver's window sums differently.
