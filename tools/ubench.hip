@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned seed)
             if (OP == 15) a[i] = (a[i] >> 8) & 0xFF00FFu;                       // 2 ops (or bfe)
             if (OP == 16) f[i] = sqrtf(f[i]);
             if (OP == 17) d[i] = (double)(float)d[i] + dc;                      // cvt pair + add
+            if (OP == 18) { f[i] = f[i] + fc; d[i] = d[i] + (double)f[i]; }     // add_f32 + cvt_f64_f32 + add_f64
+            if (OP == 19) { f[i] = f[i] + fc; d[i] = d[i] + dc; }               // add_f32 + add_f64 (the same without the conversion)
         }
     }
     unsigned r = 0;
@@ -81,5 +83,7 @@ int main()
     run<15>("lshr + and", 2, &base);
     run<16>("sqrtf (ieee)", 1, &base);
     run<17>("cvt f64->f32->f64 + add", 3, &base);
+    run<18>("add_f32 + cvt_f64_f32 + add_f64", 3, &base);
+    run<19>("add_f32 + add_f64", 2, &base);
     return 0;
 }
