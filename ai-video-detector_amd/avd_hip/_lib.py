@@ -105,6 +105,8 @@ def load() -> C.CDLL:
     L = C.CDLL(SO_PATH)
     vp, u8p, f32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.avd_abi_version.restype = C.c_int
+    if L.avd_abi_version() != 3:          # before any other symbol is bound: an older library fails HERE, with a message
+        raise ImportError("libavd_hip.so ABI version mismatch (this package binds version 3): rebuild it with `make -C csrc`")
     L.avd_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.avd_destroy.argtypes = [vp]
     L.avd_destroy.restype = None
@@ -150,8 +152,6 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         if name not in ("avd_destroy", "avd_last_error", "avd_debug_fetch"):
             getattr(L, name).restype = C.c_int
-    if L.avd_abi_version() != 2:
-        raise ImportError("libavd_hip.so ABI version mismatch")
     _lib = L
     return L
 

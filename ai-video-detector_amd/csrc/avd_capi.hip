@@ -58,7 +58,9 @@ void free_ws(Workspace& ws, bool keep_weights = false)
     F(ws.d_clipstart);
     if (ws.h_clipstart) (void)hipHostFree(ws.h_clipstart);
     for (int k = 0; k < AVD_FB_LEVELS; k++) { F(ws.d_pyr[k]); F(ws.d_poly[k]); F(ws.d_flow[k]); F(ws.d_flow2[k]); }
-    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_rec); F(ws.d_mag); F(ws.d_fbflags);
+    F(ws.d_vs); F(ws.d_vs0); F(ws.d_flow_il); F(ws.d_stats); F(ws.d_rec); F(ws.d_mag); F(ws.d_fbflags); F(ws.d_pairdiff);
+    F(ws.d_rlist); F(ws.d_vs_rerun); F(ws.d_vs0_rerun);
+    if (ws.h_rlist) (void)hipHostFree(ws.h_rlist);
     F(ws.d_vit_w); F(ws.d_vit_bias); F(ws.d_vit_patches); F(ws.d_vit_tokens);
     F(ws.d_audio_tab); F(ws.d_audio_buf); F(ws.d_audio_out);
     F(ws.d_cnn_w); F(ws.d_cnn_b); F(ws.d_cnn_img); F(ws.d_cnn_pool); F(ws.d_cnn_logits);
@@ -223,6 +225,8 @@ int avd_ws_reserve(avd_ctx* ctx, int n, int h, int w)
     return avd_ws_reserve_frames(ctx, n, rowbuf_elems_for(ws, n), lappart_elems_for(ws, n));
 }
 
+constexpr size_t kPairDiffTilesHost = 20;     // = kPairDiffTiles of avd_fb_device.h (the pyramid kernel's 160-px tiles per frame)
+
 // Farneback scratch for min(n - 1, kFbChunkMax) pairs, at least kFbChunk; grows when a call brings more pairs
 int avd_ws_reserve_fb(avd_ctx* ctx, int n)
 {
@@ -233,7 +237,9 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
         ws.fb_cap = 0;
         for (int k = 0; k < AVD_FB_LEVELS; k++) {
             const size_t plane = (size_t)(AVD_SMALL >> k) * (AVD_SMALL >> k);
-            if (int e = dev_alloc(ctx, ws.d_pyr[k], nf * plane)) return e;
+            // the 320-px scale of the pyramid exists only with fb_fold_blur off (the polynomial expansion forms that blur itself): 49 MB per 120 frames
+            if (k > 0 || !ctx->fb_fold_blur) { if (int e = dev_alloc(ctx, ws.d_pyr[k], nf * plane)) return e; }
+            else if (ws.d_pyr[0]) { (void)hipFree(ws.d_pyr[0]); ws.d_pyr[0] = nullptr; }
             if (int e = dev_alloc(ctx, ws.d_poly[k], nf * 5 * plane)) return e;
             if (int e = dev_alloc(ctx, ws.d_flow[k], np * 2 * plane)) return e;
             if (int e = dev_alloc(ctx, ws.d_flow2[k], np * 2 * plane)) return e;
@@ -242,11 +248,17 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
         if (int e = dev_alloc(ctx, ws.d_stats, np * 2)) return e;
         if (int e = dev_alloc(ctx, ws.d_mag, np * (size_t)AVD_NPIX)) return e;
         if (int e = dev_alloc(ctx, ws.d_fbflags, np)) return e;
+        if (int e = dev_alloc(ctx, ws.d_pairdiff, np * kPairDiffTilesHost)) return e;
+        if (ws.d_rlist) { (void)hipFree(ws.d_rlist); ws.d_rlist = nullptr; ws.rlist_cap = 0; }
+        if (ws.h_rlist) { (void)hipHostFree(ws.h_rlist); ws.h_rlist = nullptr; }
+        if (hipHostMalloc((void**)&ws.h_rlist, sizeof(int) * np) != hipSuccess) { ws.h_rlist = nullptr; ctx->err = "hipHostMalloc (re-run list)"; return AVD_ERR_NOMEM; }
         if (ws.d_vs) { (void)hipFree(ws.d_vs); ws.d_vs = nullptr; }
         if (ws.d_vs0) { (void)hipFree(ws.d_vs0); ws.d_vs0 = nullptr; }
         if (ws.d_flow_il) { (void)hipFree(ws.d_flow_il); ws.d_flow_il = nullptr; }
         ws.fb_cap = want;
     }
+    if (!ctx->fb_fold_blur && !ws.d_pyr[0])
+        if (int e = dev_alloc(ctx, ws.d_pyr[0], ((size_t)ws.fb_cap + 2) * AVD_NPIX)) return e;
     // the double intermediate of the two-kernel fallback (4 MB per pair): only when that path is selected
     const bool two_kernel = ctx->fb_mode == 0 && ctx->fb_fused != 0xF;
     if (two_kernel && !ws.d_vs) {
@@ -292,11 +304,38 @@ __global__ __launch_bounds__(256) void k_records(const unsigned long long* __res
     rec[f] = r;
 }
 
+// Fast mode: the pairs of the chunk in the workspace whose flag word is set (h_flags[0 .. np), as the host has just read them) go through the
+// exact kernels again (launch_farneback_rerun: enqueued, not drained).  Returns the number of such pairs, or a negative status.
+static int rerun_flagged(avd_ctx* ctx, const int* h_flags, int stride, int np)
+{
+    Workspace& ws = ctx->ws;
+    int m = 0;
+    for (int i = 0; i < np; i++)
+        if (h_flags[(size_t)i * stride] != 0) ws.h_rlist[m++] = i;
+    if (m == 0) return 0;
+    if (int e = launch_farneback_rerun(ctx, ctx->stream, ws.h_rlist, m, 0, np)) return e < 0 ? e : -1;
+    return m;
+}
+
+static void launch_records(avd_ctx* ctx, int p0, int np, int fa, const int* clipstart)
+{
+    Workspace& ws = ctx->ws;
+    kmark(ctx, AVD_K_RECORDS);
+    hipLaunchKernelGGL(k_records, dim3(p0 + np + 1 - fa), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap,
+                       (const uint8_t*)ws.d_hash, (const float*)ws.d_stats,
+                       (const int*)(ctx->fb_mode == 1 && ctx->fb_rerun ? ws.d_fbflags : nullptr), p0, ws.d_rec, fa, clipstart, 1);
+}
+
 // Farneback + stats over all n-1 pairs in chunks; pair p = (frame p, frame p+1).
+// Fast mode: the level kernels flag the pairs they cannot follow; the HOST reads the flag words and sends those pairs through the exact kernels
+// (nothing is launched when nothing is flagged -- the usual case).  For the last chunk of an asynchronous call that happens when the call is
+// drained (ctx->tail, impl_synchronize): the flags travel with the records.  A chunk that is followed by another one (> 512 pairs in a call), and
+// every chunk of a call that hands statistics straight to the host, is settled here, before its scratch is reused.
 static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h_mean, float* h_var,
                            float* h_flow_out, bool into_records, const int* records_clipstart = nullptr)
 {
     Workspace& ws = ctx->ws;
+    ctx->tail.active = 0;
     if (n < 2) return 0;
     if (int e = avd_ws_reserve_fb(ctx, n)) return e;
     const int chunk = ws.fb_cap;
@@ -304,28 +343,37 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
         if (int e = dev_alloc(ctx, ws.d_flow_il, (size_t)chunk * AVD_NPIX * 2)) return e;
     float* saved_il = ws.d_flow_il;
     if (!h_flow_out) ws.d_flow_il = nullptr;
+    const bool flagged_mode = ctx->fb_mode == 1 && ctx->fb_rerun;
+    const bool host_wants = h_mean || h_var || h_flow_out;
     int rc = 0;
     for (int p0 = 0; p0 < n - 1 && rc == 0; p0 += chunk) {
         const int np = std::min(chunk, n - 1 - p0);
+        const bool last = p0 + np >= n - 1;
         const uint8_t* base = d_small + (size_t)p0 * AVD_NPIX;
         rc = launch_farneback(ctx, ctx->stream, base, np + 1, 0, 0);
         if (rc) break;
         rc = launch_flow_stats(ctx, ctx->stream, np + 1, 0, 0);
         if (rc) break;
-        if (into_records) {
-            // frames p0 + 1 .. p0 + np, and frame 0 with the first chunk
-            const int fa = p0 == 0 ? 0 : p0 + 1;
-            kmark(ctx, AVD_K_RECORDS);
-            hipLaunchKernelGGL(k_records, dim3(p0 + np + 1 - fa), dim3(256), 0, ctx->stream, (const unsigned long long*)ws.d_lap,
-                               (const uint8_t*)ws.d_hash, (const float*)ws.d_stats,
-                               (const int*)(ctx->fb_mode == 1 && ctx->fb_rerun ? ws.d_fbflags : nullptr), p0, ws.d_rec, fa, records_clipstart, 1);
-        }
-        if (h_mean || h_var || h_flow_out) {
-            std::vector<float> st((size_t)np * 2);
+        if (flagged_mode && (!last || host_wants || !into_records)) {
             std::vector<int> fl((size_t)np, 0);
+            hipError_t e = hipMemcpyAsync(fl.data(), ws.d_fbflags, sizeof(int) * np, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = AVD_ERR_DEVICE; break; }
+            const int m = rerun_flagged(ctx, fl.data(), 1, np);
+            if (m < 0) { rc = m; break; }
+            if (!into_records) ctx->last_rerun += m;
+        }
+        // frames p0 + 1 .. p0 + np, and frame 0 with the first chunk
+        const int fa = p0 == 0 ? 0 : p0 + 1;
+        if (into_records) {
+            launch_records(ctx, p0, np, fa, records_clipstart);
+            if (flagged_mode && last && !host_wants) {
+                ctx->tail.active = 1; ctx->tail.p0 = p0; ctx->tail.np = np; ctx->tail.fa = fa; ctx->tail.n = n; ctx->tail.clipstart = records_clipstart;
+            }
+        }
+        if (host_wants) {
+            std::vector<float> st((size_t)np * 2);
             hipError_t e = hipMemcpyAsync(st.data(), ws.d_stats, sizeof(float) * 2 * np, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess && ctx->fb_mode == 1 && ctx->fb_rerun)
-                e = hipMemcpyAsync(fl.data(), ws.d_fbflags, sizeof(int) * np, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess && h_flow_out)
                 e = hipMemcpyAsync(h_flow_out + (size_t)p0 * AVD_NPIX * 2, ws.d_flow_il,
                                    sizeof(float) * 2 * AVD_NPIX * np, hipMemcpyDeviceToHost, ctx->stream);
@@ -334,7 +382,6 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
             for (int i = 0; i < np; i++) {
                 if (h_mean) h_mean[p0 + i] = st[2 * i];
                 if (h_var) h_var[p0 + i] = st[2 * i + 1];
-                ctx->last_rerun += fl[i] != 0;
             }
         }
     }
@@ -391,7 +438,7 @@ static int impl_create(int device_id, avd_ctx** out)
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->num_cus = prop.multiProcessorCount;
         if (const char* e = std::getenv("AVD_FB_FUSED")) ctx->fb_fused = (int)std::strtol(e, nullptr, 0) & 0xF;
-        if (const char* e = std::getenv("AVD_FB_FOLD_UP")) ctx->fb_fold_up = std::atoi(e) & 15;
+        if (const char* e = std::getenv("AVD_FB_FOLD_UP")) ctx->fb_fold_up = std::atoi(e) & 7;
         if (const char* e = std::getenv("AVD_FB_WIDE160")) ctx->fb_wide160 = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_FOLD_BLUR")) ctx->fb_fold_blur = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
@@ -463,6 +510,7 @@ static int impl_farneback_pairs(avd_ctx* ctx, const uint8_t* small320, int mem, 
     const uint8_t* d_small = nullptr;
     if (int e = stage_input(ctx, small320, mem, (size_t)n * AVD_NPIX, &d_small)) return e;
     ctx->last_rerun = 0;
+    ctx->kmark_used = 0;
     std::vector<float> fm_tmp;
     if (!flow_mean && !flow_var && !flow_out) { fm_tmp.resize((size_t)n - 1); flow_mean = fm_tmp.data(); }   // the chunks are drained either way
     if (int e = run_flow_chunks(ctx, d_small, n, flow_mean, flow_var, flow_out, false)) return e;
@@ -696,6 +744,21 @@ static int impl_synchronize(avd_ctx* ctx)
 {
     if (!ctx) return AVD_ERR_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->tail.active) {
+        // fast Farneback mode: the records of the call's last chunk carry the level kernels' flag words; the pairs they mark go through the
+        // exact kernels now (the workspace still holds the chunk), the chunk's records are assembled again and fetched
+        ctx->tail.active = 0;
+        Workspace& ws = ctx->ws;
+        const int p0 = ctx->tail.p0, np = ctx->tail.np, fa = ctx->tail.fa;
+        const int m = rerun_flagged(ctx, &ws.h_rec[p0 + 1].reserved, (int)(sizeof(avd_frame_record) / sizeof(int)), np);
+        if (m < 0) return m;
+        if (m > 0) {
+            launch_records(ctx, p0, np, fa, ctx->tail.clipstart);
+            HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec + fa, ws.d_rec + fa, sizeof(avd_frame_record) * (size_t)(p0 + np + 1 - fa), hipMemcpyDeviceToHost, ctx->stream));
+            if (ctx->profiling && ctx->kmark_used > 0) kmark(ctx, AVD_K_COUNT);     // close the re-run's region
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     if (ctx->pending_out) {
         std::memcpy(ctx->pending_out, ctx->ws.h_rec, sizeof(avd_frame_record) * ctx->pending_n);
         ctx->last_rerun = 0;
@@ -709,8 +772,10 @@ static int impl_synchronize(avd_ctx* ctx)
             if (ctx->kmark_id[i] < AVD_K_COUNT && hipEventElapsedTime(&ms, ctx->kmark_ev[i], ctx->kmark_ev[i + 1]) == hipSuccess)
                 ctx->kernel_ms[ctx->kmark_id[i]] += ms;
         }
+        ctx->kmark_incomplete = ctx->kmark_overflow;
     }
     ctx->kmark_used = 0;
+    ctx->kmark_overflow = 0;
     if (ctx->profiling && ctx->stage_marks == 5) {
         // stages: 0 preprocess, 1 hash+hamming+records, 2 farneback+stats (3 reported as copy-out)
         for (int i = 0; i < 4; i++) {
@@ -770,6 +835,7 @@ static int impl_stage_ms(avd_ctx* ctx, int stage, float* ms)
 static int impl_kernel_ms(avd_ctx* ctx, int id, float* ms)
 {
     if (!ctx || !ms || id < 0 || id >= AVD_K_COUNT) return AVD_ERR_ARG;
+    if (ctx->kmark_incomplete) { ctx->err = "avd_kernel_ms: the profiled call had more kernel regions than the library records (96): split it"; return AVD_ERR_ARG; }
     *ms = ctx->kernel_ms[id];
     return AVD_OK;
 }
@@ -791,6 +857,7 @@ static int64_t impl_debug_fetch(avd_ctx* ctx, const char* name, void* out, size_
     if (std::strcmp(name, "area") == 0) { src = ws.d_area; bytes = (size_t)n * 1024; }
     else if (std::strcmp(name, "small") == 0) { src = ws.d_small; bytes = (size_t)n * AVD_NPIX; }
     // the Farneback scratch holds ONE chunk (kFbChunk pairs): for longer clips these are the last chunk's buffers
+    else if ((k = level("pyr")) >= 0 && k == 0 && ctx->fb_fold_blur) { ctx->err = "pyr0 does not exist while fb_fold_blur is on (the polynomial expansion forms the 320-px blur itself)"; return AVD_ERR_ARG; }
     else if ((k = level("pyr")) >= 0) { src = ws.d_pyr[k]; bytes = (size_t)std::min(n, ws.fb_cap + 1) * (AVD_NPIX >> (2 * k)) * 4; }
     else if ((k = level("poly")) >= 0) { src = ws.d_poly[k]; bytes = (size_t)std::min(n, ws.fb_cap + 1) * 5 * (AVD_NPIX >> (2 * k)) * 4; }
     else if ((k = level("flow")) >= 0) { src = ws.flow_res[k] ? ws.flow_res[k] : ws.d_flow[k]; bytes = (size_t)std::min(std::max(n - 1, 0), ws.fb_cap) * 2 * (AVD_NPIX >> (2 * k)) * 4; }
@@ -833,8 +900,9 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (!ctx || !name) return AVD_ERR_ARG;
     if (std::strcmp(name, "fb_fused") == 0) { ctx->fb_fused = value & 0xF; return AVD_OK; }
     if (std::strcmp(name, "fb_mode") == 0) { ctx->fb_mode = value ? 1 : 0; return AVD_OK; }
-    if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 15; return AVD_OK; }
+    if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 7; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
+    if (std::strcmp(name, "fb_rerun_fused") == 0) { ctx->fb_rerun_fused = (value & 0xF) | 8; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value != 0; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { ctx->fb_fold_blur = value != 0; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
@@ -857,6 +925,7 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_mode") == 0) { *value = ctx->fb_mode; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_up") == 0) { *value = ctx->fb_fold_up; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
+    if (std::strcmp(name, "fb_rerun_fused") == 0) { *value = ctx->fb_rerun_fused; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { *value = ctx->fb_wide160; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { *value = ctx->fb_fold_blur; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { *value = ctx->cnn_tiles; return AVD_OK; }
@@ -1240,10 +1309,10 @@ int avd_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all)
 {
     if (!ctx) return AVD_ERR_ARG;
     return guarded(ctx, [&] {
-        const int rc = comm_allgather_last_records(ctx, count, all);
-        // the stream has been drained: a pending asynchronous call's own records are complete as well
-        if (rc == 0 && ctx->pending_out) return impl_synchronize(ctx);
-        return rc;
+        // a pending asynchronous call is drained FIRST: the exact re-run of the pairs its fast level kernels flagged happens there, and the
+        // records on the device are final only after it
+        if (ctx->pending_out || ctx->tail.active) { if (int e = impl_synchronize(ctx)) return e; }
+        return comm_allgather_last_records(ctx, count, all);
     });
 }
 

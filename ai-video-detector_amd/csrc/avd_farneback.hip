@@ -53,9 +53,12 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int kPyrLds = cmax(cmax(PyrGeo<3>::LDS_BYTES, PyrGeo<2>::LDS_BYTES), cmax(PyrGeo<1>::LDS_BYTES, PyrGeo<0>::LDS_BYTES));   // 29 KB
 
 // blk = frame * TILES + tile of this scale
+// pairdiff (K == 1 only, may be null): the tile also compares its source rows with the same rows of the NEXT frame and leaves "they differ" in
+// pairdiff[f * TILES + t] -- the 20 tiles of the 160-px scale read every row of the frame (with overlap), so their OR says whether pair (f, f + 1)
+// is a pair of bit-identical frames (which the fast level kernels exempt from the border-sign criterion, avd_fbfast.hip)
 template <int K>
 __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* __restrict__ small, const FbConsts* __restrict__ C,
-                                             float* __restrict__ I)
+                                             float* __restrict__ I, int n = 0, int* __restrict__ pairdiff = nullptr)
 {
     using G = PyrGeo<K>;
     constexpr int WL = G::WL, NC = G::NC, OFF = G::OFF, TR = G::TR, KS = G::KS, HALF = G::HALF, SROWS = G::SROWS;
@@ -68,10 +71,14 @@ __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* 
     const int dy0 = t * TR;
     const int y_first = (K == 0 ? dy0 : (dy0 << K) + OFF) - HALF;        // first source row (may be < 0)
     const uint8_t* img = small + (int64_t)f * AVD_NPIX;
+    const bool cmp = K == 1 && pairdiff != nullptr && f + 1 < n;       // workgroup-uniform
+    int differs = 0;
     for (int it = tid; it < SROWS * (S / 4); it += 256) {
         const int r = it / (S / 4), c4 = it - r * (S / 4);
         const int y = reflect101(y_first + r, S);
-        reinterpret_cast<unsigned*>(src[r] + PADX)[c4] = reinterpret_cast<const unsigned*>(img + y * S)[c4];
+        const unsigned v = reinterpret_cast<const unsigned*>(img + y * S)[c4];
+        reinterpret_cast<unsigned*>(src[r] + PADX)[c4] = v;
+        if (K == 1 && cmp) differs |= v != reinterpret_cast<const unsigned*>(img + AVD_NPIX + y * S)[c4];
     }
     // BORDER_REFLECT_101 columns, so that the taps below need no index arithmetic: x = -1 - i is x = 1 + i, x = S + i is S - 2 - i
     for (int it = tid; it < SROWS * 2 * HALF; it += 256) {
@@ -80,7 +87,11 @@ __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* 
         if (i < HALF) src[r][PADX - 1 - i] = g[1 + i];
         else src[r][PADX + S + (i - HALF)] = g[S - 2 - (i - HALF)];
     }
-    __syncthreads();
+    if (K == 1 && cmp) {
+        const int any = __syncthreads_or(differs);
+        if (tid == 0) pairdiff[f * tiles + t] = any;
+    } else
+        __syncthreads();
     const float* kx = C->gk[K];
     if (KS == 3) {
         // every column is filtered at these scales (x = j): a lane does four of them from three aligned words
@@ -154,8 +165,9 @@ __device__ __forceinline__ void pyramid_body(char* lds, int blk, const uint8_t* 
 // It also clears the per-pair ill-posedness flags of the chunk (the fast level kernels, which come later on the stream, set them).
 __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__ small, int n, const FbConsts* __restrict__ C,
                                                     float* __restrict__ I0, float* __restrict__ I1, float* __restrict__ I2,
-                                                    float* __restrict__ I3, int* __restrict__ flags)
+                                                    float* __restrict__ I3, int* __restrict__ flags, int* __restrict__ pairdiff)
 {
+    static_assert(PyrGeo<1>::TILES == kPairDiffTiles, "avd_fbfast.hip reads one word per 160-px tile");
     __shared__ __align__(16) char lds[kPyrLds];
     if (flags && (int)(blockIdx.x * 256 + threadIdx.x) < n - 1) flags[blockIdx.x * 256 + threadIdx.x] = 0;
     const int n3 = n * PyrGeo<3>::TILES, n2 = n * PyrGeo<2>::TILES, n1 = n * PyrGeo<1>::TILES;
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
     b -= n3;
     if (b < n2) { pyramid_body<2>(lds, b, small, C, I2); return; }
     b -= n2;
-    if (b < n1) { pyramid_body<1>(lds, b, small, C, I1); return; }
+    if (b < n1) { pyramid_body<1>(lds, b, small, C, I1, n, pairdiff); return; }
     if (I0) pyramid_body<0>(lds, b - n1, small, C, I0);     // null: the polynomial expansion forms the 320-px scale's 3 x 3 blur itself (the grid ends before)
 }
 
@@ -408,14 +420,15 @@ __global__ __launch_bounds__(320) void k_polyexp_all(PolyPtrs P, int n, const Fb
 // vertically the rows are clipped and the weights kept.  A lane produces 4 consecutive outputs.
 // ---------------------------------------------------------------------------------------
 template <int W>
-__global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev, float* __restrict__ flow, int npairs)
+__global__ __launch_bounds__(256) void k_flow_up(const float* __restrict__ prev, float* __restrict__ flow, int npairs, const int* __restrict__ plist)
 {
     constexpr int H = W, PW = W / 2, PH = H / 2, Q = W / 4;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= npairs * 2 * H * Q) return;
     const int q = gid % Q;
     const int dy = (gid / Q) % H;
-    const int pc = gid / (Q * H);                          // pair*2 + channel
+    int pc = gid / (Q * H);                                // pair*2 + channel
+    if (plist) pc = plist[pc >> 1] * 2 + (pc & 1);         // plist (may be null): the launch works on pairs plist[0 .. npairs) (exact re-run of flagged pairs)
     const float* src = prev + (int64_t)pc * PW * PH;
     float fy = dy * 0.5f - 0.25f;
     const int sy = floor_f(fy);
@@ -504,7 +517,7 @@ __host__ __device__ constexpr int d16_pair_tiles(int w) { return (d16_nyb(w) * 5
 // ---------------------------------------------------------------------------------------
 template <int W, int NPROD>
 __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
-                                                           double* __restrict__ D16, double* __restrict__ VS0, int npairs)
+                                                           double* __restrict__ D16, double* __restrict__ VS0, int npairs, const int* __restrict__ plist)
 {
     static_assert(NPROD >= 2 && NPROD <= 4 && 24 % NPROD == 0, "ring size below covers 2 to 4 producers");
     constexpr int H = W, m = 7;
@@ -523,8 +536,9 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
     // gathered R1 rows, and pair p+1 reads as R0 the frame that pair p gathers as R1, at about the same rows at
     // about the same time: so an XCD (one L2) gets all strips of a CONTIGUOUS run of pairs.
     const int sj = blockIdx.x >> 3, ppx = (npairs + 7) >> 3;
-    const int p = (blockIdx.x & 7) * ppx + sj / NSTRIP, strip = sj % NSTRIP;
-    if (sj / NSTRIP >= ppx || p >= npairs) return;
+    const int ps = (blockIdx.x & 7) * ppx + sj / NSTRIP, strip = sj % NSTRIP;
+    if (sj / NSTRIP >= ppx || ps >= npairs) return;
+    const int p = plist ? plist[ps] : ps;              // ps indexes the scratch (D, vsum columns), p the pair's R and flow
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
@@ -577,8 +591,8 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
         // wave that stores (D tiles, vsum columns 0..6): it never waits on memory.
         const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
         const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-        const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
-        const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+        const unsigned dbase = ((unsigned)ps * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+        const unsigned vbase = (unsigned)ps * 5u * H * 8u + (unsigned)(lane - 8);
         const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
         for (int k = 0; k < NPH; k++) {
             if (k >= 2 && k - 2 < NP) {
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
 
 template <int W>
 __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const float* __restrict__ flow,
-                                           double* __restrict__ D16, double* __restrict__ VS0, int npairs)
+                                           double* __restrict__ D16, double* __restrict__ VS0, int npairs, const int* __restrict__ plist)
 {
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
@@ -657,16 +671,17 @@ __global__ __launch_bounds__(128) void k_uv(const float* __restrict__ R, const f
     const int lane = threadIdx.x & 63;
     // all strips of a contiguous run of pairs on one XCD (see k_uvp)
     const int sj = blockIdx.x >> 3, ppx = (npairs + 7) >> 3;
-    const int p = (blockIdx.x & 7) * ppx + sj / NSTRIP, strip = sj % NSTRIP;
-    if (sj / NSTRIP >= ppx || p >= npairs) return;       // both waves of a strip leave together
+    const int ps = (blockIdx.x & 7) * ppx + sj / NSTRIP, strip = sj % NSTRIP;
+    if (sj / NSTRIP >= ppx || ps >= npairs) return;      // both waves of a strip leave together
+    const int p = plist ? plist[ps] : ps;                // ps indexes the scratch, p the pair's R and flow
     const int xl = strip * kStripW - 8 + lane;         // logical column of this lane
     const int x = clampi(xl, 0, W - 1);                // edge replicate = duplicate chain
 
     if (wv == 1) {
         const bool writer = lane >= 8 && lane < 8 + kStripW && xl < W;
         const bool head = strip == 0 && lane >= 8 && lane < 8 + m;
-        const unsigned dbase = ((unsigned)p * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
-        const unsigned vbase = (unsigned)p * 5u * H * 8u + (unsigned)(lane - 8);
+        const unsigned dbase = ((unsigned)ps * d16_pair_tiles(W) + (x >> 3)) * 512u + (x & 7);   // tile column of this lane
+        const unsigned vbase = (unsigned)ps * 5u * H * 8u + (unsigned)(lane - 8);
         const int lhi = min(lane + m, 63), llo = max(lane - m - 1, 0);
         for (int y0 = 0; y0 < H; y0 += 2) {
             const int y1 = y0 + 1, buf = (y0 >> 1) & 1;
@@ -792,7 +807,7 @@ __device__ __forceinline__ void chunk_commit(const ChunkRegs& r, double (*buf)[5
 
 template <int W>
 __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, const double* __restrict__ VS0,
-                                              float* __restrict__ flow, int npairs)
+                                              float* __restrict__ flow, int npairs, const int* __restrict__ plist)
 {
     constexpr int H = W, m = 7;
     constexpr int XCH = d16_xch(W), NYB = d16_nyb(H);
@@ -800,8 +815,9 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     __shared__ __align__(16) double lds[2][5][512];
     __shared__ __align__(16) float outb[2][64][20];      // row stride 80 B: ds_write_b128 of 8 lanes covers all banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = blockIdx.x / NYB, ybk = blockIdx.x - p * NYB;
-    const double* tiles = D16 + ((int64_t)p * d16_pair_tiles(W) + (int64_t)ybk * 5 * XCH) * 512;   // [c][xc][512]
+    const int ps = blockIdx.x / NYB, ybk = blockIdx.x - ps * NYB;
+    const int p = plist ? plist[ps] : ps;                // ps indexes the scratch, p the pair's flow
+    const double* tiles = D16 + ((int64_t)ps * d16_pair_tiles(W) + (int64_t)ybk * 5 * XCH) * 512;   // [c][xc][512]
 
     if (wave == 1) {
         // loader: the tile image is copied verbatim (16 B per lane, 4 KiB per channel).  Chunk xc+2 is in
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
     const int yc = min(y, H - 1);
     double g[5];
     {
-        const double* v0 = VS0 + ((int64_t)p * 5 * H + yc) * 8;
+        const double* v0 = VS0 + ((int64_t)ps * 5 * H + yc) * 8;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             const double* vc = v0 + (int64_t)c * H * 8;
@@ -934,11 +950,11 @@ __device__ __forceinline__ float chunk_total(const float* part)
 // second pass, (mag - mean)^2 with mean = sum / N in float32, runs on the registers: the magnitudes are read once.
 // (18.6 us for 119 pairs; a variant with 16-byte loads and the 16-element sum relayed over four lanes took 22.9 us.)
 // mag[pair][N] = |flow|: written by the last launch of the fast level kernel, or by k_mag below from the two flow planes
-__global__ __launch_bounds__(512) void k_stats_pair(const float* __restrict__ mag, float* __restrict__ stats)
+__global__ __launch_bounds__(512) void k_stats_pair(const float* __restrict__ mag, float* __restrict__ stats, const int* __restrict__ plist)
 {
     __shared__ float wpart[kNChunk][8];
     __shared__ float ctot[kNChunk];
-    const int p = blockIdx.x, tid = threadIdx.x;
+    const int p = plist ? plist[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const int l = tid >> 3, wave = tid >> 6;
     const bool in_last = l < ((AVD_NPIX - (kNChunk - 1) * kChunk) >> 7);          // the last buffer has 32 leaves
     const float* src = mag + (int64_t)p * AVD_NPIX + l * 128 + (tid & 7);
@@ -985,11 +1001,12 @@ __global__ __launch_bounds__(512) void k_stats_pair(const float* __restrict__ ma
 
 // mag = np.sqrt(fx * fx + fy * fy) in float32 (video.py:46) from the planar flow [pair][2][N]: the exact-mode level kernels
 // leave the flow only, the fast one writes the magnitudes itself
-__global__ void k_mag(const float* __restrict__ flow, float* __restrict__ mag, int64_t total4)
+__global__ void k_mag(const float* __restrict__ flow, float* __restrict__ mag, int64_t total4, const int* __restrict__ plist)
 {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total4) return;
-    const int64_t p = gid / (AVD_NPIX / 4), i = gid - p * (AVD_NPIX / 4);
+    const int64_t ps = gid / (AVD_NPIX / 4), i = gid - ps * (AVD_NPIX / 4);
+    const int64_t p = plist ? plist[ps] : ps;
     const float4 fx = reinterpret_cast<const float4*>(flow + p * 2 * AVD_NPIX)[i], fy = reinterpret_cast<const float4*>(flow + (p * 2 + 1) * AVD_NPIX)[i];
     float4 m;
     m.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
@@ -1022,6 +1039,7 @@ struct Seg {
     double *vs, *vs0;
     float *stats, *flow_il;
     int* flags;                          // ill-posedness flags of the segment's pairs (fast mode)
+    int* pairdiff;                       // [pair][kPairDiffTiles] "frame p differs from frame p + 1" per tile of the pyramid kernel's 160-px scale
     avd_ctx* prof;                       // non-null: record kernel events of the full-resolution blur launches
 };
 
@@ -1042,6 +1060,7 @@ static Seg make_seg(avd_ctx* ctx, hipStream_t stream, int frame_off, int pair_of
     g.vs0 = ws.d_vs0 ? ws.d_vs0 + (size_t)pair_off * 5 * S * 8 : nullptr;
     g.stats = ws.d_stats + (size_t)pair_off * 2;
     g.flags = ws.d_fbflags ? ws.d_fbflags + pair_off : nullptr;
+    g.pairdiff = ws.d_pairdiff ? ws.d_pairdiff + (size_t)pair_off * kPairDiffTiles : nullptr;
     g.flow_il = ws.d_flow_il ? ws.d_flow_il + (size_t)pair_off * AVD_NPIX * 2 : nullptr;
     return g;
 }
@@ -1063,7 +1082,7 @@ void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int
     const int wgs = n * ((fold ? 0 : PyrGeo<0>::TILES) + PyrGeo<1>::TILES + PyrGeo<2>::TILES + PyrGeo<3>::TILES);
     kmark(ctx, AVD_K_PYRAMID);
     hipLaunchKernelGGL(k_pyramid_all, dim3(wgs), dim3(256), 0, g.stream, d_small, n, C, fold ? (float*)nullptr : g.pyr_w[0], g.pyr_w[1], g.pyr_w[2],
-                       g.pyr_w[3], g.flags);
+                       g.pyr_w[3], g.flags, g.pairdiff);
     PolyPtrs P;
     P.small = fold ? d_small : nullptr;
     int grid = ((n * (S / kPolyRows) + 7) >> 3) << 3;      // the 320-px scale: kPolyRows rows per workgroup
@@ -1076,8 +1095,9 @@ void pyramid_and_polyexp(avd_ctx* ctx, const Seg& g, const uint8_t* d_small, int
 }
 
 // one FarnebackUpdateFlow_Blur iteration at level k: matrices from the current flow, box sums, solve
+// plist (may be null): the launches work on the pairs plist[0 .. np) of the segment; the double intermediate is indexed by position in the list
 template <int W>
-void blur_iteration(const Seg& g, int k, int np)
+void blur_iteration(const Seg& g, int k, int np, float* flow, const int* plist)
 {
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW;
     // AVD_UV_VARIANT (A/B knob): 0 = k_uv everywhere, 1 = k_uvp (4 producers) everywhere, 2 (default) = k_uvp
@@ -1096,15 +1116,50 @@ void blur_iteration(const Seg& g, int k, int np)
     const bool uvp_fits = np * NSTRIP <= 3 * 256;
     if (variant == 1 || (variant == 2 && (W < S || uvp_fits))) {
         hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(384), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
+                           (const float*)flow, g.vs, g.vs0, np, plist);
     } else {
         hipLaunchKernelGGL(k_uv<W>, dim3(grid), dim3(128), 0, g.stream, (const float*)g.poly[k],
-                           (const float*)g.flow[k], g.vs, g.vs0, np);
+                           (const float*)flow, g.vs, g.vs0, np, plist);
     }
     mark(); mark();
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,
-                       (const double*)g.vs0, g.flow[k], np);
+                       (const double*)g.vs0, flow, np, plist);
     mark();
+}
+
+void flow_up_level(hipStream_t stream, int k, const float* prev, float* flow, int np, const int* plist)
+{
+    const int w = S >> k;
+    const int items = np * 2 * w * (w / 4);
+    if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, flow, np, plist);
+    else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, flow, np, plist);
+    else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, flow, np, plist);
+}
+
+// the three blur iterations of level k with the EXACT kernels (literal running sums in both directions: bit-identical to the oracle), in place in
+// `flow`: the fused kernel (avd_fbfused.hip: one workgroup per pair, all three iterations in one launch) where bit k of fused_mask is set, else the
+// two-kernel path.  plist: see blur_iteration.
+int exact_level(avd_ctx* ctx, const Seg& g, int k, int np, float* flow, int fused_mask, const int* plist)
+{
+    const int w = S >> k;
+    const bool coarsest = k == AVD_FB_LEVELS - 1;
+    auto ev = [&] { if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], g.stream); };
+    if ((fused_mask >> k) & 1) {
+        ev();
+        if (int e = launch_fb_level(ctx, g.stream, w, g.poly[k], flow, np, 3, coarsest, plist)) return e;
+        ev();
+        return 0;
+    }
+    if (!g.vs) { ctx->err = "two-kernel Farneback path: scratch not reserved"; return AVD_ERR_ARG; }
+    for (int it = 0; it < 3; it++) {
+        switch (k) {
+        case 3: blur_iteration<S / 8>(g, k, np, flow, plist); break;
+        case 2: blur_iteration<S / 4>(g, k, np, flow, plist); break;
+        case 1: blur_iteration<S / 2>(g, k, np, flow, plist); break;
+        default: blur_iteration<S>(g, k, np, flow, plist); break;
+        }
+    }
+    return 0;
 }
 
 }  // namespace
@@ -1129,20 +1184,14 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
         const bool fold_chain = fast && k == 0 && (ctx->fb_fold_up & 1);
         const bool fold_pro = fast && (k == 1 || k == 2) && (ctx->fb_fold_up & 2);
         const bool one_launch = fast && (k == 2 || k == 3) && (ctx->fb_fold_up & 4);
-        // bit 3: the 160- / 80- / 40-px levels run their three iterations PIPELINED in one launch (avd_fbpipe.hip); overrides bits 1 and 2
-        const bool pipe = fast && k >= 1 && (ctx->fb_fold_up & 8);
         if (k == AVD_FB_LEVELS - 1) {
             // the coarsest level starts from zero flow: the fused kernel is told so, the two-kernel path reads a cleared buffer
             if (!fast && !((ctx->fb_fused >> k) & 1)) HIP_TRY(ctx, hipMemsetAsync(g.flow[k], 0, sizeof(float) * 2 * plane * np, stream));
-        } else if (fold_chain || (fold_pro && !pipe)) {
+        } else if (fold_chain || fold_pro) {
             // the level's first launch forms its initial flow from the previous level's (avd_fbfast.hip)
         } else {
-            const int items = np * 2 * h * (w / 4);
-            const float* prev = ctx->ws.flow_res[k + 1];
             kmark(ctx, k == 2 ? AVD_K_FLOWUP80 : (k == 1 ? AVD_K_FLOWUP160 : AVD_K_FLOWUP320));
-            if (k == 2) hipLaunchKernelGGL(k_flow_up<S / 4>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
-            else if (k == 1) hipLaunchKernelGGL(k_flow_up<S / 2>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
-            else hipLaunchKernelGGL(k_flow_up<S>, dim3((items + 255) / 256), dim3(256), 0, stream, prev, g.flow[k], np);
+            flow_up_level(stream, k, ctx->ws.flow_res[k + 1], g.flow[k], np, nullptr);
         }
         ctx->ws.flow_res[k] = g.flow[k];
         kmark(ctx, k == 3 ? AVD_K_LEVEL40 : (k == 2 ? AVD_K_LEVEL80 : (k == 1 ? AVD_K_LEVEL160 : AVD_K_LEVEL320)));
@@ -1151,56 +1200,80 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             float* a = g.flow[k];
             float* b = ctx->ws.d_flow2[k] + (size_t)pair_off * 2 * plane;
             int* fl = ctx->fb_rerun ? g.flags : nullptr;
+            const int* pd = ctx->fb_rerun ? g.pairdiff : nullptr;
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            const bool prev_in = fold_chain || (fold_pro && !pipe);          // the first launch reads the previous level's flow
+            const bool prev_in = fold_chain || fold_pro;                     // the first launch reads the previous level's flow
             const float* prev = prev_in ? ctx->ws.flow_res[k + 1] : nullptr;
-            if (pipe) {
-                if (int e = launch_fb_pipe(ctx, stream, w, g.poly[k], a, b, fl, np, k == AVD_FB_LEVELS - 1)) return e;
-                a = b;
-            } else if (one_launch) {
+            if (one_launch) {
                 // all three iterations in one launch: (prologue: prev -> a,) a -> b -> a -> b
-                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], prev_in ? prev : a, b, a, nullptr, fl, np, k == AVD_FB_LEVELS - 1, prev_in ? 4 : 3)) return e;
+                if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], prev_in ? prev : a, b, a, nullptr, fl, pd, np, k == AVD_FB_LEVELS - 1, prev_in ? 4 : 3)) return e;
                 a = b;
             } else {
                 for (int it = 0; it < 3; it++) {
                     float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
                     const bool first_prev = prev_in && it == 0;
                     const int mode = !first_prev ? 0 : (fold_chain ? 1 : 2);
-                    if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], first_prev ? prev : a, b, a, mag, fl, np, k == AVD_FB_LEVELS - 1 && it == 0, mode)) return e;
+                    if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], first_prev ? prev : a, b, a, mag, fl, pd, np, k == AVD_FB_LEVELS - 1 && it == 0, mode)) return e;
                     float* t = a; a = b; b = t;
                 }
             }
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
             ctx->ws.flow_res[k] = a;                       // the buffer written last
-            if (k == 0 && ctx->fb_rerun && g.flags) {
-                // pairs the level kernels flagged as ill-posed: all four levels again with the exact kernels' code (one launch; nothing
-                // to do for a pair that is not flagged), working in the levels' first flow buffers, result and |flow| where the
-                // statistics read them
-                float* fl4[4] = {a, g.flow[1], g.flow[2], g.flow[3]};
-                const float* Rk[4] = {g.poly[0], g.poly[1], g.poly[2], g.poly[3]};
-                kmark(ctx, AVD_K_RERUN);
-                if (int e = launch_fb_rerun(ctx, stream, Rk, fl4, ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX, g.flags, np)) return e;
-            }
+            // (pairs the level kernels flagged as ill-posed are re-run by the exact kernels once the HOST has seen the flags: launch_farneback_rerun)
             continue;
         }
-        if (!((ctx->fb_fused >> k) & 1) && !g.vs) { ctx->err = "two-kernel Farneback path: scratch not reserved"; return AVD_ERR_ARG; }
         // ctx->fb_fused (AVD_FB_FUSED / avd_set_option "fb_fused"): bit k set = level k runs the fused kernel (avd_fbfused.hip: all three iterations in one launch,
-        // D never leaves the chip); clear = the two-kernel path below
-        if ((ctx->fb_fused >> k) & 1) {
-            if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            if (int e = launch_fb_level(ctx, stream, w, g.poly[k], g.flow[k], np, 3, k == AVD_FB_LEVELS - 1)) return e;
-            if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
-            continue;
-        }
-        for (int it = 0; it < 3; it++) {
-            switch (k) {
-            case 3: blur_iteration<S / 8>(g, k, np); break;
-            case 2: blur_iteration<S / 4>(g, k, np); break;
-            case 1: blur_iteration<S / 2>(g, k, np); break;
-            default: blur_iteration<S>(g, k, np); break;
-            }
-        }
+        // D never leaves the chip); clear = the two-kernel path
+        if (int e = exact_level(ctx, g, k, np, g.flow[k], ctx->fb_fused, nullptr)) return e;
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// Exact re-run (fast mode) of the m pairs h_list[0 .. m) of the chunk the workspace still holds (polynomial expansions of all its frames): the four
+// levels with the exact kernels from a compacted pair list, then |flow| and the two statistics of those pairs, where the record kernel reads
+// them.  The HOST calls this after it has seen the chunk's flag words (avd_capi.hip): nothing is launched for a chunk without flagged pairs, and the
+// work is sized by their number -- up to kRerunTwoKernelMax pairs the 160- / 320-px levels run the two-kernel path (a pair spread over seven strips /
+// 64-row bands: ~0.15 ms per level for one pair, where the fused kernel's single workgroup per pair takes 0.23 / 0.83 ms however few pairs there are),
+// beyond that the fused kernels (one workgroup per pair = the exact mode's own launches, its time for a clip of nothing but flagged pairs).
+// ctx->fb_rerun_fused (tuning / tests): level mask of the fused kernel for the few-pairs case, default 0xC (40 and 80 px).
+int launch_farneback_rerun(avd_ctx* ctx, hipStream_t stream, const int* h_list, int m, int pair_off, int np_chunk)
+{
+    if (m <= 0) return 0;
+    Workspace& ws = ctx->ws;
+    if (m > ws.fb_cap) { ctx->err = "re-run list longer than the chunk"; return AVD_ERR_ARG; }
+    if (!ws.d_rlist) {
+        if (int e = dev_alloc(ctx, ws.d_rlist, (size_t)ws.fb_cap)) return e;
+        ws.rlist_cap = ws.fb_cap;
+    }
+    const bool few = m <= kRerunTwoKernelMax;
+    const int fused_mask = few ? (ctx->fb_rerun_fused & 0xF) : 0xF;
+    if (fused_mask != 0xF && !ws.d_vs_rerun) {
+        if (int e = dev_alloc(ctx, ws.d_vs0_rerun, (size_t)kRerunTwoKernelMax * 5 * S * 8)) return e;
+        if (int e = dev_alloc(ctx, ws.d_vs_rerun, (size_t)kRerunTwoKernelMax * (5 * AVD_NPIX + 512))) return e;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_rlist, h_list, sizeof(int) * m, hipMemcpyHostToDevice, stream));
+    Seg g = make_seg(ctx, stream, 0, pair_off);
+    g.prof = nullptr;
+    g.vs = ws.d_vs_rerun; g.vs0 = ws.d_vs0_rerun;         // indexed by position in the list
+    const int* plist = ws.d_rlist;
+    kmark(ctx, AVD_K_RERUN);
+    for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
+        // levels 3 .. 1 work in the level's first flow buffer, level 0 in the buffer the fast kernels left their final flow in (the one the
+        // caller may read back)
+        float* flow = k == 0 ? const_cast<float*>(ws.flow_res[0]) : g.flow[k];
+        if (k == AVD_FB_LEVELS - 1) {
+            if (!((fused_mask >> k) & 1)) { ctx->err = "exact re-run: the coarsest level runs the fused kernel (it needs no cleared flow)"; return AVD_ERR_ARG; }
+        } else {
+            flow_up_level(stream, k, g.flow[k + 1], flow, m, plist);
+        }
+        if (int e = exact_level(ctx, g, k, m, flow, fused_mask, plist)) return e;
+    }
+    float* mg = ws.d_mag + (size_t)pair_off * AVD_NPIX;
+    launch1d(k_mag, (int64_t)m * (AVD_NPIX / 4), 256, stream, (const float*)ws.flow_res[0], mg, (int64_t)m * (AVD_NPIX / 4), plist);
+    hipLaunchKernelGGL(k_stats_pair, dim3(m), dim3(512), 0, stream, (const float*)mg, g.stats, plist);
+    if (g.flow_il)                                        // the caller wants the dense flow (tests / debugging): interleave the chunk again
+        launch1d(k_flow_interleave, (int64_t)np_chunk * AVD_NPIX, 256, stream, (const float*)ws.flow_res[0], g.flow_il, (int64_t)np_chunk * AVD_NPIX);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -1213,8 +1286,8 @@ int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, in
     const float* fl = ctx->ws.flow_res[0] ? ctx->ws.flow_res[0] : g.flow[0];
     float* mg = ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX;
     kmark(ctx, AVD_K_STATS);
-    if (!ctx->ws.mag_valid) launch1d(k_mag, (int64_t)np * (AVD_NPIX / 4), 256, stream, fl, mg, (int64_t)np * (AVD_NPIX / 4));
-    hipLaunchKernelGGL(k_stats_pair, dim3(np), dim3(512), 0, stream, (const float*)mg, g.stats);
+    if (!ctx->ws.mag_valid) launch1d(k_mag, (int64_t)np * (AVD_NPIX / 4), 256, stream, fl, mg, (int64_t)np * (AVD_NPIX / 4), (const int*)nullptr);
+    hipLaunchKernelGGL(k_stats_pair, dim3(np), dim3(512), 0, stream, (const float*)mg, g.stats, (const int*)nullptr);
     if (g.flow_il)
         launch1d(k_flow_interleave, (int64_t)np * AVD_NPIX, 256, stream, fl, g.flow_il, (int64_t)np * AVD_NPIX);
     HIP_TRY(ctx, hipGetLastError());

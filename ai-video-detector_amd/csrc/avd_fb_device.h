@@ -280,11 +280,29 @@ __device__ __forceinline__ void ne_products(const float (&r)[5], float scale, fl
     M[4] = r6 * r2 + r5 * r3;
 }
 
-// ---- shared by the fast level kernels (avd_fbfast.hip, avd_fbpipe.hip) ----------------------------------------------
-// thresholds of the ill-posedness criterion (see role_solve in avd_fbfast.hip)
+// ---- shared by the fast level kernels (avd_fbfast.hip) -------------------------------------------------------------
+// thresholds of the ill-posedness criteria (see role_solve and role_ne in avd_fbfast.hip)
 constexpr double kCondMax = 2000.;
 constexpr float kFlowMax = 0.3f;
+// border-sign criterion (round 5, role_ne): a flow component below kTinyFlow in magnitude is of the size of cv2's own running-sum residue
+// (<= ~1e-13 px), so its SIGN -- which decides "inside" / "outside" at the top / left border -- is not reproducible; kJumpMin: how much the
+// two branches must differ at that pixel for the flip to matter
+constexpr float kTinyFlow = 1e-12f;
+constexpr float kJumpMin = 1e-6f;    // a non-zero component below kTinyFlow
+constexpr float kJumpMinZero = 0.05f; // an exactly zero one (cv2's may be +-residue): two different FLAT frames, whose zero flow is structural, stay below
+constexpr int kPairDiffTiles = 20;   // tiles per frame of the pyramid kernel's 160-px scale: each leaves "frame f differs from frame f + 1 here"
 
+// What FarnebackUpdateMatrices' two branches disagree by at a pixel whose deciding flow component is (all but) zero: "outside" takes
+// r2 = R0[0] / 2, r3 = R0[1] / 2, r4 .. r6 from R0 alone, "inside" (R0[0] - b[0]) / 2, .., (R0[2] + b[2]) / 2 .. with b the sample of R1, which is
+// the top-left gathered pixel there -> max(|b0|, |b1|, |R0[2] - b2|, |R0[3] - b3|, |R0[4] - b4|).  Cold path of role_ne; the same definition in
+// tools/experiments/fb_illposed_exp.c (border_ind).
+__device__ __forceinline__ float ne_branch_jump(const NeIn& in, const NeG2& g)
+{
+    float j = fmaxf(fabsf(g.t0.x), fabsf(g.t0.y));
+    j = fmaxf(j, fabsf(in.r0[2] - g.t0.z));
+    j = fmaxf(j, fabsf(in.r0[3] - g.t0.w));
+    return fmaxf(j, fabsf(in.r0[4] - g.t1.x));
+}
 
 // 1 / d as the compiler's IEEE division sequence computes it (v_rcp_f64, two Newton steps, a correction of the quotient)
 // minus its scaling and fix-up instructions: they only act on denormal / huge / special operands, and d is a determinant

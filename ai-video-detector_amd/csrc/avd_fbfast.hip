@@ -115,9 +115,17 @@ __device__ __forceinline__ void fb_barrier() { __syncthreads(); }
 // UP: the flow of this launch is the previous level's, resized: the chain wave leaves row y of it in fring[y & 15] at least
 // one step before it is wanted here (see role_chain); it is fetched from there one entry before the gather that needs it.
 // ZF (compile time: only the coarsest level's first iteration has it): the flow is known to be zero whatever the buffer holds
+// Border-sign criterion (round 5; the second ill-posedness criterion, the first is in role_solve).  cv2's warp is discontinuous at the top / left
+// border: at x = 0 a flow dx = -tiny gives x1 = -1, "outside" (the normal equations are formed from R0 alone), dx = +tiny gives x1 = 0, "inside"
+// (average with R1); likewise dy at y = 0.  A component below kTinyFlow is of the size of the rounding residue of cv2's own running sums -- its
+// sign is an artefact of their summation order, which this kernel does not share -- so where the two branches differ at such a pixel (ne_branch_jump)
+// the pair can only be reproduced by the exact kernels: bit 4 + level of flags[p].  Derived on the CPU (tools/experiments/fb_illposed_exp.c,
+// border_ind; profiles/r05_experiments.md section 1): it closes the checkerboard residual of round 4 (exactly periodic or static content, where
+// the true flow is zero and everything is residue) and fires on no natural / noisy / letterboxed pair of the 3 120-pair experiment.
+// chk (wave-uniform): flags are kept and the pair's two frames are not bit-identical (an exact duplicate's zero flow is structural in cv2 too).
 template <typename Ge, bool UP, bool ZF = false>
 __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
-                                        const float* __restrict__ fring, int p, int x, int k, int lane)
+                                        const float* __restrict__ fring, int p, int x, int k, int lane, int* __restrict__ flags, bool chk)
 {
     constexpr bool zf = ZF;
     constexpr int W = Ge::W, GD = Ge::GD, EPS = Ge::EPS;
@@ -133,6 +141,9 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     auto row_of = [](int e) { return e < H - 1 ? e : H - 1; };
     NeIn in[NIS];
     NeG2 g[NGS];
+    const bool xz = x == 0;                                // this lane's column decides inside / outside by the sign of dx
+    const bool chkx = chk && __builtin_amdgcn_ballot_w64(xz) != 0;   // wave-uniform: only the first block of the first strip holds column 0
+    bool ill = false;
     auto gather = [&](const NeIn& s, int row, NeG2& gs) __attribute__((always_inline)) { ne_gather2(R, r1base, s, x, row, W, H, gs, zf); };
     auto flow_of = [&](int row, NeIn& s) { const float* f = fring + (row & 15) * Ge::F_SLOT + lane; s.dx = f[0]; s.dy = f[64]; };
     auto load_in = [&](int row, NeIn& s) {
@@ -165,6 +176,16 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
             __builtin_amdgcn_sched_barrier(0);
             float a[5];                                                      // r2 .. r6: the chain wave attenuates and multiplies (PN: done here)
             ne_finish_r(in[ii % NIS], g[ii % NGS], x, e, W, H, a, zf);
+            if constexpr (!ZF) {                                             // (ZF: the coarsest level's first flow is zero in cv2 as well)
+                if (chkx || (chk && e == 0)) {
+                    const NeIn& s = in[ii % NIS];
+                    const bool tx = chkx && xz && fabsf(s.dx) < kTinyFlow, ty = e == 0 && fabsf(s.dy) < kTinyFlow;
+                    if (__builtin_amdgcn_ballot_w64(tx | ty) != 0) {         // cold: rows / columns of residue-sized flow
+                        const float jump = ne_branch_jump(s, g[ii % NGS]);
+                        ill |= (tx && jump > (s.dx == 0.f ? kJumpMinZero : kJumpMin)) | (ty && jump > (s.dy == 0.f ? kJumpMinZero : kJumpMin));
+                    }
+                }
+            }
             float* dst = mring + (e & 7) * Ge::M_SLOT + lane;
             if constexpr (Ge::PN) {
                 float mm[5];
@@ -193,6 +214,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
         work(t0 + q, q);
     }
     for (int t = TN; t < Ge::T; t++) fb_barrier();
+    if (chk && __builtin_amdgcn_ballot_w64(ill) != 0 && lane == 0) atomicOr(flags + p, 16 << (Ge::W == 320 ? 0 : Ge::W == 160 ? 1 : Ge::W == 80 ? 2 : 3));
     FBF_WAIT_OUT(threadIdx.x >> 6, k, fbf_t0)
 }
 
@@ -448,8 +470,8 @@ __device__ __forceinline__ void phase_sync()
 //     between flow_out and flow_tmp through L2, one workgroup barrier between iterations; the result is in flow_out (IT odd).
 template <typename Ge, bool UP, int IT = 1, bool PRO = false>
 __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* flow_in, float* flow_out, float* flow_tmp,
-                                                              float* __restrict__ mag_out, int* __restrict__ flags, int npairs, int nstrips, int ow,
-                                                              int zero_first, int dbg)
+                                                              float* __restrict__ mag_out, int* __restrict__ flags, const int* __restrict__ pairdiff,
+                                                              int npairs, int nstrips, int ow, int zero_first, int dbg)
 {
     constexpr int W = Ge::W, NB = Ge::NB;
     static_assert(IT == 1 || IT == 3, "one iteration per launch, or all three");
@@ -466,6 +488,9 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     const int p = (blockIdx.x & 7) * ppx + local / nstrips;
     const int s = local % nstrips;
     if (p >= npairs) return;                              // whole workgroup
+    // a pair that an earlier launch (or another strip, a moment ago) has flagged is re-run by the exact kernels whatever happens here: skip it
+    // (a clip of nothing but such pairs then costs the exact mode's time, not the sum of both)
+    if (flags && __builtin_nontemporal_load(flags + p) != 0) return;
     const int o0 = s * ow;
     const int width = o0 + ow <= W ? ow : W - o0;         // output columns of this strip (multiples of 4)
     // Waves w, w + 4, w + 8 of a workgroup share a SIMD.  Issue cycles per step: X ~ 900 (double), N ~ 550, C ~ 230: with
@@ -499,12 +524,15 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     }
     const float* fin0 = PRO ? flow_tmp : flow_in;
     if (role < Ge::NPB) {
+        // border-sign criterion: not for a pair of bit-identical frames (the pyramid kernel left "frame p differs from frame p + 1" per tile)
+        bool chk = flags != nullptr;
+        if (chk && pairdiff) chk = __builtin_amdgcn_ballot_w64(lane < kPairDiffTiles && pairdiff[p * kPairDiffTiles + (lane < kPairDiffTiles ? lane : 0)] != 0) != 0;
 #pragma unroll 1
         for (int it = 0; it < IT; it++) {
             if (it > 0) phase_sync();
             const float* fin = it == 0 ? fin0 : ((it & 1) ? flow_out : flow_tmp);
-            if (Ge::W == 40 && zero_first != 0 && it == 0) role_ne<Ge, UP, Ge::W == 40>(R, fin, mring, fring, p, x, role, lane);
-            else role_ne<Ge, UP, false>(R, fin, mring, fring, p, x, role, lane);
+            if (Ge::W == 40 && zero_first != 0 && it == 0) role_ne<Ge, UP, Ge::W == 40>(R, fin, mring, fring, p, x, role, lane, flags, chk);
+            else role_ne<Ge, UP, false>(R, fin, mring, fring, p, x, role, lane, flags, chk);
         }
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
@@ -526,8 +554,8 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
 // iteration behind a prologue that resizes the previous level's flow into flow_tmp; 3 = all three iterations (flow_in ignored when
 // zero_first, result in flow_out); 4 = prologue + all three iterations
 template <typename Ge>
-void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* ftmp, float* mag, int* flags, int np, int nstrips, int ow,
-                 int zero_first, int mode)
+void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fout, float* ftmp, float* mag, int* flags, const int* pairdiff, int np,
+                 int nstrips, int ow, int zero_first, int mode)
 {
     const int grid = 8 * ((np + 7) / 8) * nstrips;
     static const int dbg = [] { const char* e = std::getenv("AVD_FBF_DBG"); return e ? std::atoi(e) : 0; }();   // tuning experiments
@@ -535,18 +563,18 @@ void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fo
     // the chain wave's resize only exists where it pays: at 320 px it costs the launch 3.5 us and saves k_flow_up's 37; the small
     // levels are latency-bound on exactly the chain wave that would do it (160 px: 45 -> 84 us per launch against 12 saved)
     if constexpr (Ge::W == 320) {
-        if (mode == 1) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, 0, dbg); return; }
+        if (mode == 1) { hipLaunchKernelGGL((k_fb_fast<Ge, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, 0, dbg); return; }
     }
     if constexpr (Ge::W == 160 || Ge::W == 80) {
-        if (mode == 2) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 1, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, 0, dbg); return; }
+        if (mode == 2) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 1, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, 0, dbg); return; }
     }
     if constexpr (Ge::W == 80) {
-        if (mode == 4) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, 0, dbg); return; }
+        if (mode == 4) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, 0, dbg); return; }
     }
     if constexpr (Ge::W == 80 || Ge::W == 40) {
-        if (mode == 3) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, zero_first, dbg); return; }
+        if (mode == 3) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, zero_first, dbg); return; }
     }
-    hipLaunchKernelGGL((k_fb_fast<Ge, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, np, nstrips, ow, zero_first, dbg);
+    hipLaunchKernelGGL((k_fb_fast<Ge, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, zero_first, dbg);
 }
 
 }  // namespace
@@ -557,9 +585,11 @@ void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fo
 // prologue, through flow_tmp); 3 / 4 all three iterations in one launch (80 / 40 px: a pair is one workgroup), result in flow_out,
 // flow_tmp as the second buffer (4: behind the prologue).
 // mag_out (320-px level, last iteration; else null): float[pair][320][320] receives |flow|
-// flags (may be null): int[np]; bit k of flags[p] is set when level k (0 = 320 px) of pair p met the ill-posedness criterion
+// flags (may be null): int[np]; bit k of flags[p] is set when level k (0 = 320 px) of pair p met the solver's ill-posedness criterion, bit 4 + k when it met
+// the border-sign criterion; a pair whose word is already non-zero is skipped.  pairdiff (may be null): int[np][kPairDiffTiles], non-zero where frame p
+// differs from frame p + 1 (k_pyramid_all): bit-identical pairs are exempt from the border-sign criterion
 int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* flow_tmp, float* mag_out,
-                   int* flags, int np, int zero_first, int mode)
+                   int* flags, const int* pairdiff, int np, int zero_first, int mode)
 {
     if (np <= 0) return 0;
     const bool ok = mode == 0 || (mode == 1 && w == 320) || (mode == 2 && (w == 160 || w == 80)) || (mode == 3 && (w == 80 || w == 40)) || (mode == 4 && w == 80);
@@ -569,7 +599,7 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
     case 320:
         // (neighbour-shared gathers -- each lane loads its left pixel, the right one comes from lane + 1 by a DPP wave shift -- were built,
         // bit-identical and slower, 164 us per launch against 142: profiles/r04_experiments.md section 2; the code is in the history, commit 3e8b43a)
-        launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, np, 2, 160, zero_first, mode);
+        launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, pairdiff, np, 2, 160, zero_first, mode);
         break;
     case 160:
         // two shapes (ctx->fb_wide160, default 1): a pair as ONE strip of three blocks with the 320-px level's wave mix (119 workgroups of 12 waves,
@@ -577,11 +607,11 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
         // (one clip alone: -25 us); the wide one costs fewer CU-microseconds (119 x 58 against 238 x 48: lanes 91 % instead of 73 % on image
         // columns, 14 halo columns per pair instead of 28) and that is what counts with clips in flight: +2.4 % frames/s.  The two differ in the
         // grouping of the solver's window sums (four columns per lane against two): bit-identical on well-posed content, like the 320-px level.
-        if (ctx->fb_wide160) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 160, zero_first, mode);
-        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 2, 80, zero_first, mode);
+        if (ctx->fb_wide160) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 160, zero_first, mode);
+        else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 2, 80, zero_first, mode);
         break;
-    case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 80, zero_first, mode); break;
-    case 40: launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, np, 1, 40, zero_first, mode); break;
+    case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 80, zero_first, mode); break;
+    case 40: launch_fast<FGeo<40, 1, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 40, zero_first, mode); break;
     default: ctx->err = "launch_fb_fast: unsupported level size"; return AVD_ERR_ARG;
     }
     HIP_TRY(ctx, hipGetLastError());

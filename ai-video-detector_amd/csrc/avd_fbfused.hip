@@ -436,7 +436,7 @@ __device__ __forceinline__ void level_body(const float* __restrict__ R, float* _
 
 template <int W, int K, int G>
 __global__ __launch_bounds__((64 * Geo<W, K, G>::NWAVES)) void k_fb_level(const float* __restrict__ R, float* __restrict__ flow,
-                                                                        int npairs, int iterations, int dbg_arg, int zero_first)
+                                                                        int npairs, int iterations, int dbg_arg, int zero_first, const int* __restrict__ plist)
 {
 #ifdef AVD_FB_DEBUG
     const int dbg = dbg_arg;                              // timing experiments (AVD_FB_DBG), see launch_fb_level
@@ -449,138 +449,23 @@ __global__ __launch_bounds__((64 * Geo<W, K, G>::NWAVES)) void k_fb_level(const 
     // consecutive pairs share a frame (pair p gathers as R1 what pair p+1 reads as R0): an XCD (one L2) gets a
     // contiguous run of pairs; workgroups are dealt round-robin to the 8 XCDs
     const int ppx = (npairs + 7) >> 3;
-    const int p = (blockIdx.x & 7) * ppx + (blockIdx.x >> 3);
-    if (p >= npairs) return;                              // whole workgroup
+    const int pi = (blockIdx.x & 7) * ppx + (blockIdx.x >> 3);
+    if (pi >= npairs) return;                             // whole workgroup
+    const int p = plist ? plist[pi] : pi;                 // (exact re-run of the flagged pairs of the fast mode: a compacted list)
     level_body<W, K, G>(R, flow, lds, p, iterations, dbg, zero_first, lane, wave);
 }
 
 template <int W, int K, int G>
-void launch_one(hipStream_t stream, int grid, const float* R, float* flow, int np, int iterations, int dbg, int zero_first)
+void launch_one(hipStream_t stream, int grid, const float* R, float* flow, int np, int iterations, int dbg, int zero_first, const int* plist)
 {
-    hipLaunchKernelGGL((k_fb_level<W, K, G>), dim3(grid), dim3(64 * Geo<W, K, G>::NWAVES), 0, stream, R, flow, np, iterations, dbg, zero_first);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Re-run of the pairs the fast level kernel (avd_fbfast.hip) flagged as ill-posed: ONE launch, one workgroup per pair of the
-// chunk; a workgroup whose pair is not flagged returns at once (the usual case: the launch costs a few microseconds).  A
-// flagged pair goes through all four pyramid levels with the exact level kernels' code (literal running sums in both
-// directions: bit-identical to the oracle), the x 2 resize of the flow between levels (k_flow_up's arithmetic) and the
-// |flow| plane of the 320-px level done by the same workgroup, into the buffers the flow statistics read.
-// ------------------------------------------------------------------------------------------------------------------
-struct RerunArgs {
-    const float* R[4];          // polynomial expansions per level (0 = 320 px), frames [pair], [pair + 1]
-    float* flow[4];             // per level: the pair's working flow, updated in place; flow[0] is where the result is read from
-    float* mag;                 // [pair][320 * 320]
-    const int* flags;           // [pair]
-    int npairs;
-};
-
-// cv2.resize(prev, (W, W), INTER_LINEAR) * 2 of one pair's flow (both components): k_flow_up's arithmetic, all threads
-template <int W>
-__device__ __forceinline__ void flow_up_pair(const float* __restrict__ prev, float* __restrict__ flow, int tid, int nthreads)
-{
-    constexpr int H = W, PW = W / 2, PH = H / 2, Q = W / 4;
-    for (int gid = tid; gid < 2 * H * Q; gid += nthreads) {
-        const int q = gid % Q;
-        const int dy = (gid / Q) % H;
-        const int c = gid / (Q * H);
-        const float* src = prev + c * PW * PH;
-        float fy = dy * 0.5f - 0.25f;
-        const int sy = floor_f(fy);
-        fy -= sy;
-        const float* r0 = src + clampi(sy, 0, PH - 1) * PW;
-        const float* r1 = src + clampi(sy + 1, 0, PH - 1) * PW;
-        const float b0 = 1.f - fy, b1 = fy;
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int dx = q * 4 + i;
-            float fx = dx * 0.5f - 0.25f;
-            int sx = floor_f(fx);
-            fx -= sx;
-            if (sx < 0) { fx = 0; sx = 0; }
-            bool edge = false;                                  // dx >= xmax: value copied, no weights
-            if (sx + 1 >= PW) { edge = true; if (sx >= PW - 1) { fx = 0; sx = PW - 1; } }
-            const int x1 = min(sx + 1, PW - 1);
-            const float a0 = 1.f - fx, a1 = fx;
-            float d0, d1;
-            if (edge) { d0 = r0[sx] * 1.f; d1 = r1[sx] * 1.f; }
-            else { d0 = r0[sx] * a0 + r0[x1] * a1; d1 = r1[sx] * a0 + r1[x1] * a1; }
-            o[i] = (d0 * b0 + d1 * b1) * 2.f;
-        }
-        *reinterpret_cast<flt4*>(flow + (c * H + dy) * W + q * 4) = flt4{o[0], o[1], o[2], o[3]};
-    }
-}
-
-// between two stages of the re-run: the workgroup's stores have left its waves, everyone has arrived; the level bodies
-// invalidate the L1 themselves where a flow row cached earlier would be stale (workgroup scope: one CU, one write-through L1)
-__device__ __forceinline__ void rerun_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-__global__ __launch_bounds__(512) void k_fb_rerun(RerunArgs a)
-{
-    __shared__ __align__(16) double lds[Geo<320, 4, 2>::LDS_DOUBLES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int dbg = 0;
-    // a workgroup needs a whole CU (160 KB of LDS, 512 threads at 256 registers): the grid is SMALL (kRerunGrid workgroups, each
-    // taking pairs blockIdx.x, + gridDim.x, ...) so that the usual case -- nothing flagged -- does not make 119 workgroups wait for
-    // 119 CUs to drain while other clips' kernels run (three clips in flight: 19 us per clip with one workgroup per pair)
-    for (int p = blockIdx.x; p < a.npairs; p += gridDim.x) {
-    if (a.flags[p] == 0) continue;                        // whole workgroup
-    rerun_sync();                                         // (a previous pair of this workgroup: LDS is reused)
-    float* f3 = a.flow[3] + (size_t)p * 2 * 40 * 40;
-    float* f2 = a.flow[2] + (size_t)p * 2 * 80 * 80;
-    float* f1 = a.flow[1] + (size_t)p * 2 * 160 * 160;
-    float* f0 = a.flow[0] + (size_t)p * 2 * 320 * 320;
-    level_body<40, 1, 4>(a.R[3], a.flow[3], lds, p, 3, dbg, 1, lane, wave);
-    rerun_sync();
-    flow_up_pair<80>(f3, f2, tid, 512);
-    rerun_sync();
-    level_body<80, 1, 4>(a.R[2], a.flow[2], lds, p, 3, dbg, 0, lane, wave);
-    rerun_sync();
-    flow_up_pair<160>(f2, f1, tid, 512);
-    rerun_sync();
-    level_body<160, 2, 4>(a.R[1], a.flow[1], lds, p, 3, dbg, 0, lane, wave);
-    rerun_sync();
-    flow_up_pair<320>(f1, f0, tid, 512);
-    rerun_sync();
-    level_body<320, 4, 2>(a.R[0], a.flow[0], lds, p, 3, dbg, 0, lane, wave);
-    rerun_sync();
-    // |flow| as np.sqrt(fx * fx + fy * fy) forms it in float32 (video.py:46)
-    float* mg = a.mag + (size_t)p * 320 * 320;
-    for (int i = tid; i < 320 * 320 / 4; i += 512) {
-        const flt4 fx = reinterpret_cast<const flt4*>(f0)[i], fy = reinterpret_cast<const flt4*>(f0 + 320 * 320)[i];
-        flt4 m;
-        m.x = sqrtf(fx.x * fx.x + fy.x * fy.x);
-        m.y = sqrtf(fx.y * fx.y + fy.y * fy.y);
-        m.z = sqrtf(fx.z * fx.z + fy.z * fy.z);
-        m.w = sqrtf(fx.w * fx.w + fy.w * fy.w);
-        reinterpret_cast<flt4*>(mg)[i] = m;
-    }
-    }
+    hipLaunchKernelGGL((k_fb_level<W, K, G>), dim3(grid), dim3(64 * Geo<W, K, G>::NWAVES), 0, stream, R, flow, np, iterations, dbg, zero_first, plist);
 }
 
 }  // namespace
 
 // one launch = all iterations of one pyramid level for `np` pairs; R = polynomial expansions of np + 1 frames
-// ([frame][y][x][5]), flow planar [pair][2][y][x] (initial flow in, final flow out)
-int launch_fb_rerun(avd_ctx* ctx, hipStream_t stream, const float* const R[4], float* const flow[4], float* mag, const int* flags, int np)
-{
-    if (np <= 0) return 0;
-    RerunArgs a;
-    for (int k = 0; k < 4; k++) { a.R[k] = R[k]; a.flow[k] = flow[k]; }
-    a.mag = mag; a.flags = flags; a.npairs = np;
-    constexpr int kRerunGrid = 32;
-    hipLaunchKernelGGL(k_fb_rerun, dim3(np < kRerunGrid ? np : kRerunGrid), dim3(512), 0, stream, a);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
-}
-
-int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first)
+// ([frame][y][x][5]), flow planar [pair][2][y][x] (initial flow in, final flow out); plist (may be null): the pairs are plist[0 .. np)
+int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first, const int* plist)
 {
     if (np <= 0) return 0;
     const int grid = 8 * ((np + 7) / 8);
@@ -589,12 +474,12 @@ int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, flo
     static const int var = [] { const char* e = std::getenv("AVD_FB_VARIANT"); return e ? std::atoi(e) : 0; }();
     switch (w) {
     case 320:
-        if (var == 1) launch_one<320, 2, 2>(stream, grid, R, flow, np, iterations, dbg, zero_first);      // A/B: two segments (slower)
-        else launch_one<320, 4, 2>(stream, grid, R, flow, np, iterations, dbg, zero_first);
+        if (var == 1) launch_one<320, 2, 2>(stream, grid, R, flow, np, iterations, dbg, zero_first, plist);      // A/B: two segments (slower)
+        else launch_one<320, 4, 2>(stream, grid, R, flow, np, iterations, dbg, zero_first, plist);
         break;
-    case 160: launch_one<160, 2, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first); break;
-    case 80: launch_one<80, 1, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first); break;
-    case 40: launch_one<40, 1, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first); break;
+    case 160: launch_one<160, 2, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first, plist); break;
+    case 80: launch_one<80, 1, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first, plist); break;
+    case 40: launch_one<40, 1, 4>(stream, grid, R, flow, np, iterations, dbg, zero_first, plist); break;
     default: ctx->err = "launch_fb_level: unsupported level size"; return AVD_ERR_ARG;
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -126,7 +126,11 @@ struct Workspace {
     const float* flow_res[AVD_FB_LEVELS] = {};   // where the last call left the final flow of each level (d_flow or d_flow2)
     float* d_mag = nullptr;               // [n-1][320*320] |flow| of the full-resolution level (written by the fast level kernel, or by k_mag in exact mode)
     int mag_valid = 0;                    // d_mag holds the magnitudes of the chunk being processed
-    int* d_fbflags = nullptr;             // [n-1] ill-posedness flags of the fast level kernel (bit k: level k); such pairs are re-run exactly
+    int* d_fbflags = nullptr;             // [n-1] ill-posedness flags of the fast level kernels (bit k: level k met the solver's criterion, bit 4 + k: the border-sign criterion); such pairs are re-run exactly
+    int* d_pairdiff = nullptr;            // [n-1][20] "frame p differs from frame p + 1" per tile of the pyramid kernel's 160-px scale (all zero: bit-identical frames)
+    int* d_rlist = nullptr; int rlist_cap = 0;                  // exact re-run: the flagged pairs of a chunk, compacted by the host
+    int* h_rlist = nullptr;                                     // pinned staging of that list
+    double* d_vs_rerun = nullptr; double* d_vs0_rerun = nullptr; // the two-kernel path's double intermediate for kRerunTwoKernelMax pairs (allocated by the first re-run)
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
     float* d_flow_il = nullptr;           // [n-1][320*320][2] interleaved (cv2 layout)
@@ -166,6 +170,8 @@ struct avd_ctx {
     hipEvent_t kmark_ev[96] = {};
     int kmark_id[96] = {};
     int kmark_used = 0;
+    int kmark_incomplete = 0;                  // the same for the call whose times kernel_ms holds
+    int kmark_overflow = 0;                    // a call recorded more regions than kmark_ev holds (reset when the marks are)
     float kernel_ms[AVD_K_COUNT] = {};
     float stage_ms[6] = {};
     std::string err;
@@ -185,18 +191,23 @@ struct avd_ctx {
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan
     int fb_fold_up = 5;             // fast mode, bit mask (no effect on results; AVD_FB_FOLD_UP / avd_set_option): 1 the 320-px level's first launch resizes the
                                     // 160-px flow itself (no k_flow_up<320>), 2 the 160- / 80-px levels do so in a prologue, 4 the 80- / 40-px levels run their three
-                                    // iterations in one launch, 8 (overrides 2 and 4) the 160- / 80- / 40-px levels run their three iterations PIPELINED in one launch
-                                    // (avd_fbpipe.hip; bit-identical on well-posed content, measured no faster: off by default)
+                                    // iterations in one launch
     int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
                                     // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
-    int fb_rerun = 1;               // fast mode: pairs the level kernel flags as ill-posed are re-run by the exact kernels (k_fb_rerun); 0 = A/B, tests
+    int fb_rerun = 1;               // fast mode: pairs the level kernels flag as ill-posed are re-run by the exact kernels (launch_farneback_rerun); 0 = A/B, tests
+    int fb_rerun_fused = 0xC;       // exact re-run of FEW pairs (<= kRerunTwoKernelMax): level mask of the fused kernel (bit 3 = 40 px must be set), the other levels run the two-kernel path
     int last_rerun = 0;             // pairs re-run by the last drained call
+    // the last Farneback chunk of an asynchronous call, whose flags the host has not seen yet (impl_synchronize re-runs its flagged pairs)
+    struct { int active = 0, p0 = 0, np = 0, fa = 0, n = 0; const int* clipstart = nullptr; } tail;
 };
 
 // profiling only (avd_set_profiling): the region that starts here on the context's stream is kernel `id`
 inline void kmark(avd_ctx* ctx, int id)
 {
-    if (!ctx->profiling || ctx->kmark_used >= 96) return;
+    // the last slot is kept for the closing mark (AVD_K_COUNT): a call with more regions than slots loses its LATER regions' split (they are
+    // accounted to the region of mark 94), never the end of the timeline; kmark_overflow says so (avd_kernel_ms fails then)
+    if (!ctx->profiling) return;
+    if (ctx->kmark_used >= 96 || (ctx->kmark_used == 95 && id != AVD_K_COUNT)) { ctx->kmark_overflow = 1; return; }
     hipEvent_t& e = ctx->kmark_ev[ctx->kmark_used];
     if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; return; }
     if (hipEventRecord(e, ctx->stream) == hipSuccess) ctx->kmark_id[ctx->kmark_used++] = id;
@@ -253,19 +264,18 @@ int comm_allgather_last_records(avd_ctx* ctx, int count, avd_frame_record* all);
 int launch_audio_features(avd_ctx* ctx, const float* d_wav, int64_t n, int win, avd_audio_window* d_out, int nwin);
 // avd_fbfused.hip: all blur iterations of one pyramid level (w = 40 / 80 / 160 / 320) in one launch, one workgroup per pair
 // zero_first: the initial flow is zero whatever the buffer holds (the coarsest level: no clearing launch)
-int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first);
+// plist (may be null): the launch works on pairs plist[0 .. np)
+int launch_fb_level(avd_ctx* ctx, hipStream_t stream, int w, const float* R, float* flow, int np, int iterations, int zero_first, const int* plist = nullptr);
 // avd_fbfast.hip: blur iterations of one pyramid level, a pair spread over several workgroups (column strips), the horizontal window sums
 // formed directly in double (the vertical chain stays literal).  mode 0: one iteration flow_in -> flow_out; 1 / 2: the same with flow_in =
 // the coarser level's flow, resized on the fly (320 px: by the chain wave; 160 / 80 px: in a prologue through flow_tmp); 3 / 4: all three
 // iterations in one launch (80 / 40 px), result in flow_out, flow_tmp the second buffer (4: behind the prologue)
 int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, float* flow_tmp, float* mag_out,
-                   int* flags, int np, int zero_first, int mode);
-// avd_fbpipe.hip: all three blur iterations of a small level (w = 160 / 80 / 40) pipelined in one launch; flow_in = the level's initial flow
-// (ignored when zero_first), flow_out != flow_in receives the final one; bit-identical to the one-iteration launches of avd_fbfast.hip
-int launch_fb_pipe(avd_ctx* ctx, hipStream_t stream, int w, const float* R, const float* flow_in, float* flow_out, int* flags, int np, int zero_first);
-// avd_fbfused.hip: re-run of the pairs with flags[p] != 0 through all four levels with the exact kernels' code, one launch; R / flow per
-// level (0 = 320 px); flow[k] is scratch for k > 0, flow[0] receives the result ([pair][2][320][320]), mag its magnitudes
-int launch_fb_rerun(avd_ctx* ctx, hipStream_t stream, const float* const R[4], float* const flow[4], float* mag, const int* flags, int np);
+                   int* flags, const int* pairdiff, int np, int zero_first, int mode);
+// avd_farneback.hip: exact re-run of the m flagged pairs h_list[0 .. m) (pair indices inside the chunk the workspace holds; h_list pinned) -- all four
+// levels with the exact kernels' launches from a compacted list, |flow| and the statistics of those pairs; np_chunk = pairs of the chunk
+constexpr int kRerunTwoKernelMax = 32;
+int launch_farneback_rerun(avd_ctx* ctx, hipStream_t stream, const int* h_list, int m, int pair_off, int np_chunk);
 // avd_norm.hip (extensions): LayerNorm over rows of 256..2048 values, softmax over rows of logits; device pointers
 int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps);
 int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols);

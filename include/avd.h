@@ -46,7 +46,7 @@ enum avd_mem { AVD_MEM_HOST = 0, AVD_MEM_DEVICE = 1 };
 
 #define AVD_SMALL 320          /* video.py:43 resize target */
 #define AVD_HASH 32            /* video.py:36 aHash size */
-#define AVD_ABI_VERSION 2
+#define AVD_ABI_VERSION 3      /* 3 (round 5): avd_frame_record.reserved is a criterion / level mask, option "fb_rerun_fused", "fb_fold_up" is a 3-bit mask */
 
 /* One record per sampled frame: everything video.py:36-57 derives from pixels.
  * The scalar tail (tex variance, ai_susp, summary, timeline; video.py:54-83) is
@@ -57,7 +57,9 @@ typedef struct avd_frame_record {
     float   flow_mean;   /* np.mean(|flow|) vs the previous sampled frame (video.py:47); 0 for frame 0 */
     float   flow_var;    /* np.var(|flow|)                                 (video.py:48); 0 for frame 0 */
     int32_t ham;         /* popcount(hash ^ prev_hash)     (video.py:38); -1 for frame 0 */
-    int32_t reserved;    /* non-zero: the pair (previous frame, this frame) was flagged ill-posed by the fast Farneback kernel and re-run exactly */
+    int32_t reserved;    /* non-zero: the pair (previous frame, this frame) was flagged ill-posed by the fast Farneback kernels and re-run exactly.
+                          * bit k (0 = 320 px .. 3 = 40 px): level k met the solver's criterion; bit 4 + k: the border-sign criterion.  Levels a pair
+                          * skipped because it was flagged already leave no bit. */
 } avd_frame_record;      /* 32 bytes */
 
 int avd_abi_version(void);
@@ -258,22 +260,31 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
 /* Tuning / test switches.  "fb_mode": 1 (default; environment AVD_FB_MODE=fast) = the fast Farneback level kernel
  * (csrc/avd_fbfast.hip: a pair is spread over several workgroups; cv2's vertical running sums are kept literally, the
  * horizontal 15-column window sums are formed directly in double instead of as cv2's running double sum: the flow equals
- * the exact kernels' bit for bit on well-posed inputs, within 1e-5 px otherwise) WITH the re-run of ill-posed pairs: a pair
- * whose 2 x 2 normal equations are singular over whole regions (determinant cancellation above 2000, or a displacement
- * above 0.3 of the level width; see csrc/avd_fbfast.hip) is chaotic in the reference itself, is recognised by the level
- * kernel and computed again by the exact kernels before its flow is read, so its results are the exact kernels', bit for
- * bit.  avd_frame_record.reserved is non-zero for the frame that closes such a pair; avd_get_option "rerun_pairs" counts
- * them for the last drained call.  Stated guarantee of the mode: flow_mean / flow_var within rel 1e-6 and ai_susp within
- * 1e-6 of the oracle (north_star: 1e-4), tests/test_gpu_fbfast.py + the content soak in tests/test_gpu_soak.py; the
- * one family outside it that the soak found is named there (exactly periodic checkerboards shifted by whole pixels: the reference's own
- * flow moves by more than this library's deviation under one ulp of input noise; fb_mode = exact reproduces them bit for bit).
- * "fb_rerun" (default 1, environment AVD_FB_RERUN): 0 switches the re-run off (A/B, tests).
+ * the exact kernels' bit for bit on well-posed inputs, within 1e-5 px otherwise) WITH the exact re-run of the pairs it cannot follow.
+ * Two criteria, evaluated by the level kernels at every pixel, iteration and level (derivation: profiles/r04_experiments.md section 1,
+ * profiles/r05_experiments.md section 1; tools/experiments/fb_illposed_run.py):
+ *   solver      the 2 x 2 normal equations are singular over whole regions -- determinant cancellation above 2000, or a displacement
+ *               above 0.3 of the level width: the reference's own flow is chaotic there (ramps, stripes, isolated straight edges);
+ *   border sign a flow component at the top / left image border is smaller than 1e-12 px (the size of the rounding residue of cv2's own
+ *               running sums) while cv2's warp decides "inside the image" / "outside" by its SIGN and the two branches differ there:
+ *               exactly periodic or static content whose true flow is zero (checkerboards; bit-identical frames but for a small patch).
+ *               A pair of bit-identical frames is exempt (its zero flow is structural in cv2 too).
+ * The host reads the flag words (with the records) and sends flagged pairs through the exact kernels before anything is handed to the caller,
+ * so their results are the exact kernels', bit for bit: nothing is launched when nothing is flagged; up to 32 flagged pairs of a chunk run the
+ * 160- / 320-px levels through the two-kernel path (a pair spread over many workgroups), more run the fused kernels (one workgroup per pair: a
+ * clip of nothing but flagged pairs costs the exact mode's time -- a flagged pair leaves the fast launches at once).
+ * avd_frame_record.reserved is non-zero for the frame that closes such a pair; avd_get_option "rerun_pairs" counts
+ * them for the last drained call.  Stated guarantee of the mode, with no exception for any content: flow_mean / flow_var within rel 1e-6 and
+ * ai_susp within 1e-6 of the oracle (north_star: 1e-4), tests/test_gpu_fbfast.py + the content soak over 28 families in tests/test_gpu_soak.py.
+ * "fb_rerun" (default 1, environment AVD_FB_RERUN): 0 switches the re-run off (A/B, tests).  "fb_rerun_fused" (default 0xC): level mask of the
+ * fused kernel in the few-pairs re-run (bit 3 is always set); no effect on results.
  * 0 (AVD_FB_MODE=exact) = the exact kernels, bit-identical to the oracle everywhere, one workgroup per pair.
- * "fb_fold_up" (fast mode, default 1, environment AVD_FB_FOLD_UP; no effect on results): the first launch of the 320-px level
- * resizes the 160-px level's flow itself instead of reading the output of a separate resize launch.
+ * "fb_fold_up" (fast mode, bit mask, default 5, environment AVD_FB_FOLD_UP; no effect on results): 1 = the first launch of the 320-px level
+ * resizes the 160-px level's flow itself instead of reading the output of a separate resize launch; 2 = the 160- and 80-px levels do so in a
+ * prologue of their first launch; 4 = the 80- and 40-px levels (a pair is one workgroup there) run their three iterations in one launch.
  * "fb_fold_blur" (default 1, environment AVD_FB_FOLD_BLUR; no effect on results): the 3 x 3 Gaussian of the 320-px pyramid scale is formed inside
  * the polynomial expansion (same two float passes, same operation order) instead of being written by the pyramid kernel and read back;
- * avd_debug_copy "pyr0" is meaningful with the option off only.
+ * avd_debug_fetch "pyr0" exists with the option off only (an error otherwise: the buffer is not even allocated).
  * "fb_wide160" (fast mode, default 1, environment AVD_FB_WIDE160): the 160-px level runs a pair as ONE strip of three 64-column blocks
  * (119 workgroups, fewer CU-microseconds: +2.4 % frames/s with clips in flight) instead of two 80-column strips (238 workgroups, each
  * launch 10 us shorter: one clip alone finishes ~25 us sooner).  Same guarantee; the two shapes group the solver's window sums differently.
@@ -292,14 +303,15 @@ int avd_get_option(avd_ctx* ctx, const char* name, int* value);
 int avd_stage_ms(avd_ctx* ctx, int stage, float* ms);
 /* Per-kernel device time (ms) of the LAST drained avd_analyze_* call with profiling on: HIP events on the context's stream in
  * front of every kernel (group) of the path; a level's figure is the sum of its launches (fast mode: three, one per blur
- * iteration).  bench.py's roofline.kernels is built from these, with clips run alone. */
+ * iteration).  bench.py's roofline.kernels is built from these, with clips run alone.  A call with more kernel regions than the library
+ * records (96: ~40 clips in one batch) makes avd_kernel_ms fail rather than report partial sums. */
 enum avd_kernel_id {
     AVD_K_PREPROCESS = 0,  /* k_preprocess_vec / k_preprocess_nv12 (+ staging copies of host input) */
     AVD_K_HASH,            /* k_hash: 32 x 32 INTER_AREA cells, mean threshold, moment reduction */
     AVD_K_PYRAMID,         /* k_pyramid_all: Gaussian blur + decimation, four scales */
     AVD_K_POLYEXP,         /* k_polyexp_all: polynomial expansion, four scales */
     AVD_K_LEVEL40, AVD_K_FLOWUP80, AVD_K_LEVEL80, AVD_K_FLOWUP160, AVD_K_LEVEL160, AVD_K_FLOWUP320, AVD_K_LEVEL320,
-    AVD_K_RERUN,           /* k_fb_rerun: exact re-run of the pairs flagged ill-posed (returns at once when none is) */
+    AVD_K_RERUN,           /* exact re-run of the pairs the fast level kernels flagged (launched when the call is drained; 0 when none was) */
     AVD_K_STATS,           /* k_stats_pair (exact mode: + k_mag) */
     AVD_K_RECORDS,         /* k_records: Hamming distances, record assembly */
     AVD_K_OTHER,           /* clip-table upload, records copy-out */

@@ -1,8 +1,9 @@
 """Seeded content families for the Farneback parity soak: name -> generator(rng) -> (prev, next), two uint8[320, 320]
 frames as video.py:43 would hand them to cv2.calcOpticalFlowFarneback (video.py:45).  Natural-looking content (smooth and
 1/f fields with translation, zoom / rotation, fades, scene cuts, letter- and pillar-boxing, saturation, blockiness, text),
-degenerate content (flat, constant, steps, gradients) and adversarial content (ramps, stripes, checkerboards: singular or
-chaotic normal equations).  Test infrastructure: used by tests/test_gpu_soak.py and tools/experiments/fb_illposed_run.py.
+degenerate content (flat, constant, steps, gradients), adversarial content (ramps, stripes, checkerboards of any cell size, with and
+without overlays: singular or chaotic normal equations) and static scenes (fresh noise per frame; bit-identical frames but for a small
+patch, as a screen recording has them).  Test infrastructure: used by tests/test_gpu_soak.py and tools/experiments/fb_illposed_run.py.
 """
 import numpy as np
 
@@ -228,5 +229,50 @@ def families():
         dx, dy = rng.integers(0, 9, 2)
         return u8(f[:S, :S]), u8(f[dy:dy + S, dx:dx + S])
     fam["blocky"] = blocky
+
+    def static_noise(rng):
+        """a static textured scene with fresh sensor noise in every frame (no motion at all)"""
+        f = crop(smooth(rng, rng.choice([2.5, 5.0])), 0, 0)
+        n = int(rng.integers(1, 4))
+        return u8(f, rng, n), u8(f, rng, n)
+    fam["static_noise"] = static_noise
+
+    def static_local_change(rng):
+        """screen-recording-like: two bit-identical frames except for a small patch that changes (cursor, clock digit)"""
+        a = u8(crop(pink(rng, 1.2), 0, 0))
+        b = a.copy()
+        y, x = rng.integers(20, 290, 2)
+        hh, ww = rng.integers(1, 12, 2)
+        b[y:y + hh, x:x + ww] = np.clip(b[y:y + hh, x:x + ww].astype(int) + int(rng.integers(-60, 61)), 0, 255).astype(np.uint8)
+        return a, b
+    fam["static_local_change"] = static_local_change
+
+    def checker_any(rng):
+        """checkerboards of ANY cell size (2 .. 80 px, not only powers of two), shifted by up to two cells: exactly periodic content whose
+        true flow is zero wherever the frames alias -- everything cv2 computes there is the rounding residue of its running sums"""
+        c = int(rng.integers(2, 81))
+        yy, xx = np.mgrid[0:S + 200, 0:S + 200]
+        f = (((yy // c) + (xx // c)) % 2 * int(rng.integers(60, 256))).astype(np.float64)
+        dx, dy = rng.integers(0, 2 * c + 1, 2)
+        return u8(f[:S, :S]), u8(f[dy:dy + S, dx:dx + S])
+    fam["checker_any"] = checker_any
+
+    def checker_overlay(rng):
+        """a checkerboard that is NOT exactly periodic: a static logo, one pixel off by one grey level, or +-1 noise on top"""
+        c = int(rng.choice([2, 4, 16, 32, 64]))
+        yy, xx = np.mgrid[0:S + 200, 0:S + 200]
+        f = (((yy // c) + (xx // c)) % 2 * int(rng.integers(60, 256))).astype(np.uint8)
+        dx, dy = rng.integers(0, c + 1, 2)
+        a, b = f[:S, :S].copy(), f[dy:dy + S, dx:dx + S].copy()
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            a[10:20, 10:30] = 77
+            b[10:20, 10:30] = 77
+        elif kind == 1:
+            a[int(rng.integers(0, S)), int(rng.integers(0, S))] ^= 1
+        else:
+            a, b = u8(a, rng, 1), u8(b, rng, 1)
+        return a, b
+    fam["checker_overlay"] = checker_overlay
 
     return fam

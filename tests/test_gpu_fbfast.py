@@ -3,7 +3,8 @@ app/analyzers/video.py:45).
 
   fb_mode = 1 "fast"  (default, csrc/avd_fbfast.hip): cv2's vertical running sums literally, the horizontal 15-column
                       window sums formed directly in double instead of as cv2's running double sum -- and every pair the
-                      kernel flags as ILL-POSED re-run by the exact kernels (k_fb_rerun) before its flow is read.
+                      kernels flag as ILL-POSED re-run by the exact kernels (the host reads the flag words and launches
+                      them for a compacted list: launch_farneback_rerun) before anything is handed to the caller.
                       Guarantee asserted here, with NO exception for any pair: flagged pairs bit-identical to the oracle
                       (they ARE the exact kernels' result); the others dense flow max |delta| <= 1e-5 px (in practice 0
                       differing values), flow_mean / flow_var relative 1e-6; ai_susp |delta| <= 1e-6 (north_star: 1e-4);
@@ -168,13 +169,7 @@ def test_folded_launches_are_bit_identical(oracle):
     320-px level's first launch forms its initial flow from the 160-px level's on the fly (cv2: resize x 2, INTER_LINEAR, times 2)
     instead of reading what k_flow_up wrote; 2 = the 160- and 80-px levels do the same in a prologue of their first launch; 4 = the
     80- and 40-px levels run their three iterations in ONE launch (flow handed over through L2 between iterations).  On smooth
-    clips, on white noise and on the hard set (flows of hundreds of pixels, first / last columns and rows).
-
-    8 = the three small levels PIPELINED (csrc/avd_fbpipe.hip; built, measured no faster than 5, which is the default): the same arithmetic per pixel, but its solver
-    lanes sum a window for FOUR output columns at a time where the small levels' one-iteration kernels do two -- another grouping of
-    the same double additions.  On well-posed content every one of those sums is exact and the flow is bit-identical (asserted);
-    on the hard set's three ill-posed pairs the last double bit differs and chaos does the rest, but those pairs are the ones the
-    default mode re-runs exactly: with the re-run on, everything is bit-identical again (asserted, with the same pairs re-run)."""
+    clips, on white noise and on the hard set (flows of hundreds of pixels, first / last columns and rows)."""
     import avd_hip
     sets = [_smalls(oracle, synth.make_clip(5, 360, 640, seed=21, dup_every=3)), synth.random_frames(4, 320, 320, seed=5)[..., 1].copy(),
             _hard_frames()]
@@ -186,30 +181,89 @@ def test_folded_launches_are_bit_identical(oracle):
         c.set_option("fb_mode", 1)
         assert c.get_option("fb_fold_up") == 5
         for si, frames in enumerate(sets):
-            hard = si == 2
             c.set_option("fb_rerun", 0)                    # the fast kernels themselves, on every pair
             c.set_option("fb_fold_up", 0)
             fm0, fv0, flow0 = c.farneback_pairs(frames, want_flow=True)
             lvl0 = levels(c, len(frames))
-            for mask in (1, 2, 4, 6, 7) + (() if hard else (8, 9, 13)):
+            for mask in (1, 2, 4, 6, 7):
                 c.set_option("fb_fold_up", mask)
                 fm1, fv1, flow1 = c.farneback_pairs(frames, want_flow=True)
                 assert np.array_equal(flow0.view(np.uint32), flow1.view(np.uint32)), mask
                 assert np.array_equal(fm0, fm1) and np.array_equal(fv0, fv1), mask
                 for k, lv in enumerate(levels(c, len(frames))):            # and the final flow of every pyramid level
                     assert np.array_equal(lv.view(np.uint32), lvl0[k].view(np.uint32)), (mask, k)
-            if hard:
-                c.set_option("fb_rerun", 1)
-                c.set_option("fb_fold_up", 1)
-                fm0, fv0, flow0 = c.farneback_pairs(frames, want_flow=True)
-                n0 = c.get_option("rerun_pairs")
-                for mask in (8, 9, 13):
-                    c.set_option("fb_fold_up", mask)
-                    fm1, fv1, flow1 = c.farneback_pairs(frames, want_flow=True)
-                    assert c.get_option("rerun_pairs") == n0 >= 3, mask
-                    assert np.array_equal(flow0.view(np.uint32), flow1.view(np.uint32)), mask
-                    assert np.array_equal(fm0, fm1) and np.array_equal(fv0, fv1), mask
             c.set_option("fb_fold_up", 5)
+
+
+def _flagged_mix(n_pairs, seed):
+    """frames whose consecutive pairs alternate between content the level kernels flag (ramps rolled, stripes, 2-px checkerboards against
+    their inverse) and content they do not (smooth translation)"""
+    from tests.content_families import families
+    fam = families()
+    rng = np.random.default_rng(seed)
+    names = ["ramp_roll", "smooth_shift", "stripes", "checker", "pink_shift"]
+    frames = []
+    while len(frames) < n_pairs + 1:
+        a, b = fam[names[(len(frames) // 2) % len(names)]](rng)
+        frames += [a, b]
+    return np.stack(frames[:n_pairs + 1])
+
+
+def test_rerun_paths_are_the_exact_kernels(ctxs, oracle):
+    """The exact re-run of flagged pairs from a compacted list: few pairs (the 160- / 320-px levels through the two-kernel path, every
+    choice of the level mask fb_rerun_fused), many pairs (> 32 flagged: the fused kernels, one workgroup per pair), through both entry points
+    (avd_farneback_pairs settles a chunk at once; avd_analyze_frames when the call is drained).  A flagged pair's flow is the exact mode's,
+    bit for bit; the unflagged ones keep the tolerance."""
+    import avd_hip
+    for n_pairs, seed in ((9, 3), (80, 4)):
+        frames = _flagged_mix(n_pairs, seed)
+        xm, xv, xflow = ctxs["exact"].farneback_pairs(frames, want_flow=True)
+        if n_pairs <= 9:
+            for p in range(n_pairs):
+                assert np.array_equal(xflow[p], oracle.farneback(frames[p], frames[p + 1])), p
+        clip = np.repeat(frames[..., None], 3, axis=3)
+        with avd_hip.Context(0) as c:
+            for mask in ((0x8, 0xC, 0xF, 0xA) if n_pairs <= 9 else (0xC,)):
+                c.set_option("fb_rerun_fused", mask)
+                fm, fv, flow = c.farneback_pairs(frames, want_flow=True)
+                m = c.get_option("rerun_pairs")
+                rec = c.analyze_frames(clip)
+                flagged = np.nonzero(rec["reserved"][1:])[0]
+                assert len(flagged) == m == c.get_option("rerun_pairs") and m >= (3 if n_pairs <= 9 else 33), (n_pairs, hex(mask), m)
+                for p in range(n_pairs):
+                    if rec["reserved"][p + 1]:
+                        assert np.array_equal(flow[p].view(np.uint32), xflow[p].view(np.uint32)), (n_pairs, hex(mask), p)
+                        assert fm[p] == xm[p] and fv[p] == xv[p], (n_pairs, hex(mask), p)
+                    else:
+                        assert np.abs(flow[p] - xflow[p]).max() <= FLOW_TOL, (n_pairs, hex(mask), p)
+                    assert rec["flow_mean"][p + 1] == fm[p] and rec["flow_var"][p + 1] == fv[p], (n_pairs, hex(mask), p)
+
+
+def test_rerun_across_chunks_and_in_batches(ctxs):
+    """More pairs than the Farneback scratch holds (512): every chunk's flagged pairs are settled before the scratch is reused; and a batch
+    of clips (one launch sequence over all their pairs): the records equal the exact mode's on flagged pairs, the tolerance elsewhere."""
+    import avd_hip
+    frames = _flagged_mix(560, 9)
+    xm, xv = ctxs["exact"].farneback_pairs(frames)
+    with avd_hip.Context(0) as c:
+        fm, fv = c.farneback_pairs(frames)
+        assert c.get_option("rerun_pairs") >= 150
+        np.testing.assert_allclose(fm, xm, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(fv, xv, rtol=1e-6, atol=1e-7)
+        clip = np.repeat(frames[..., None], 3, axis=3)
+        rec = c.analyze_frames(clip)
+        flagged = rec["reserved"][1:] != 0
+        assert flagged.sum() == c.get_option("rerun_pairs") >= 150
+        assert np.array_equal(rec["flow_mean"][1:][flagged], xm[flagged]) and np.array_equal(rec["flow_var"][1:][flagged], xv[flagged])
+        np.testing.assert_allclose(rec["flow_mean"][1:], xm, rtol=1e-6, atol=1e-7)
+        # a batch: three clips of 7 / 30 / 12 frames cut out of the same material
+        cuts = [(0, 7), (40, 70), (100, 112)]
+        recs = c.analyze_batch([clip[a:b] for a, b in cuts])
+        for (a, b), r in zip(cuts, recs):
+            assert r["ham"][0] == -1 and r["flow_mean"][0] == 0
+            f = r["reserved"][1:] != 0
+            assert np.array_equal(r["flow_mean"][1:][f], xm[a:b - 1][f]) and np.array_equal(r["flow_var"][1:][f], xv[a:b - 1][f])
+            np.testing.assert_allclose(r["flow_mean"][1:], xm[a:b - 1], rtol=1e-6, atol=1e-7)
 
 
 def test_level_shapes_are_bit_identical(oracle):

@@ -2,21 +2,21 @@
 (reference site: cv2.calcOpticalFlowFarneback + np.mean / np.var of |flow|, app/analyzers/video.py:45-48, and ai_susp,
 video.py:54-56).
 
-288 seeded pairs of 320 x 320 frames from the 24 content families of tests/content_families.py: natural-looking (smooth /
-1/f fields with translation, zoom, rotation, fades, scene cuts, letter- and pillar-boxing, saturation, blocks, text),
-degenerate (flat, constant, steps, gradients) and adversarial (ramps, stripes, checkerboards).  Asserted per pair:
-flow_mean / flow_var within rel 1e-6 (abs 1e-7) of the oracle and |delta ai_susp| <= 1e-6 for the texture value that makes
-ai_susp most sensitive to the flow (tex -> infinity: ai_susp = 1 - (1 + mot), so |delta ai_susp| = |delta flow_mean|).
-The CPU experiment behind the flag criterion (tools/experiments/fb_illposed_run.py, 1 440 pairs) is the same generator.
+Seeded pairs of 320 x 320 frames from every content family of tests/content_families.py (28 families x 12 pairs by default):
+natural-looking (smooth / 1/f fields with translation, zoom, rotation, fades, scene cuts, letter- and pillar-boxing,
+saturation, blocks, text), static scenes (fresh noise per frame; bit-identical frames but for a small patch), degenerate (flat,
+constant, steps, gradients) and adversarial (ramps, stripes, checkerboards of any cell size, with and without overlays).
+Asserted for EVERY pair, no family excepted: flow_mean / flow_var within rel 1e-6 (abs 1e-7) of the oracle and |delta ai_susp| <= 1e-6
+for the texture value that makes ai_susp most sensitive to the flow (tex -> infinity: ai_susp = 1 - (1 + mot), so |delta ai_susp| =
+|delta flow_mean|); fb_mode = exact bit-identical.  The CPU experiment behind the two flag criteria
+(tools/experiments/fb_illposed_run.py, 3 120 pairs) is the same generator.
 
-KNOWN RESIDUAL, kept in the soak and reported, not hidden: exactly periodic checkerboards shifted by whole pixels (family
-"checker": cells of 2 .. 32 px).  Their normal equations are well conditioned but where the two frames alias the right-hand
-side is pure rounding residue (every window sum cancels exactly in exact arithmetic), so the oracle's own flow moves by
-1e-4 .. 1e-1 relative under one ulp of input noise while neither criterion fires.  fb_mode = exact reproduces them bit for bit
-(asserted); in the default mode a checkerboard pair outside the tolerance is checked against the oracle's own +-1-ulp
-sensitivity instead (3 of the 60 checkerboard pairs of the 1 440-pair run, profiles/r04_soak_1440.txt; 2 x 2 cells are the
-worst: 5e-2 relative).
+Round 4 kept a carve-out here for exactly periodic checkerboards, keyed on the family's name.  Round 5 found the mechanism (cv2's
+warp takes "inside" or "outside" at the top / left border by the SIGN of a flow component that is pure rounding residue of its
+running sums) and the level kernels flag it (avd_fbfast.hip, role_ne): the carve-out is gone.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -24,17 +24,7 @@ pytestmark = pytest.mark.gpu
 
 from tests.content_families import families  # noqa: E402
 
-import os
-
-PER_FAMILY = int(os.environ.get("AVD_SOAK_PER_FAMILY", "12"))   # 12 x 24 families = 288 pairs; larger one-off runs: profiles/r04_soak_1440.txt
-
-
-def _is_checker(name):
-    return name == "checker"
-
-
-def _close(got, want):
-    return abs(float(got) - float(want)) <= max(1e-6 * abs(float(want)), 1e-7)
+PER_FAMILY = int(os.environ.get("AVD_SOAK_PER_FAMILY", "12"))   # larger one-off runs: profiles/r05_soak_*.txt
 
 
 def test_default_mode_on_every_content_family(oracle):
@@ -49,32 +39,23 @@ def test_default_mode_on_every_content_family(oracle):
         cx.set_option("fb_mode", 0)
         fm, fv = c.farneback_pairs(frames)                     # pairs (2k, 2k + 1) are the soak; the ones in between are ignored
         rerun_total = c.get_option("rerun_pairs")
+        rec = c.analyze_frames(np.repeat(frames[..., None], 3, axis=3))   # the same pairs through the records: which were re-run, and why
         xm, xv = cx.farneback_pairs(frames)
-    worst, reruns, residual = 0.0, {}, []
-    lib = oracle.lib()
+    worst, reruns = 0.0, {}
     for k, (name, seed) in enumerate(jobs):
         a, b = frames[2 * k], frames[2 * k + 1]
-        flow = oracle.farneback(a, b)
-        m, v = oracle.flow_stats(flow)
+        m, v = oracle.flow_stats(oracle.farneback(a, b))
         assert xm[2 * k] == m and xv[2 * k] == v, ("exact", name, seed)           # exact mode: bit-identical on every family
         dm = abs(float(fm[2 * k]) - float(m))
-        if _is_checker(name) and not (_close(fm[2 * k], m) and _close(fv[2 * k], v)):
-            sens_m = sens_v = 0.0
-            try:
-                for model in (2, 4):
-                    lib.avdo_set_model(model)
-                    mm, vv = oracle.flow_stats(oracle.farneback(a, b))
-                    sens_m = max(sens_m, abs(float(mm) - float(m)))
-                    sens_v = max(sens_v, abs(float(vv) - float(v)))
-            finally:
-                lib.avdo_set_model(0)
-            dv = abs(float(fv[2 * k]) - float(v))
-            residual.append((seed, dm, sens_m, dv, sens_v))
-            assert dm <= 4 * max(sens_m, 1e-6) and dv <= 4 * max(sens_v, 1e-6), (name, seed, dm, sens_m, dv, sens_v)
-            continue
         worst = max(worst, dm)
         assert fm[2 * k] == pytest.approx(m, rel=1e-6, abs=1e-7), (name, seed, float(fm[2 * k]), float(m))
         assert fv[2 * k] == pytest.approx(v, rel=1e-6, abs=1e-7), (name, seed, float(fv[2 * k]), float(v))
         assert dm <= 1e-6 * max(1.0, abs(m)), (name, seed, dm)               # |delta ai_susp| bound at tex -> infinity
-    print(f"[soak] {len(jobs)} pairs, {len(fam)} families: max |delta flow_mean| = {worst:.3g}; pairs re-run in the call "
-          f"(incl. the in-between pairs): {rerun_total}; checkerboard residual (seed, |delta mean|, oracle +-1 ulp, |delta var|, oracle +-1 ulp): {residual}")
+        assert rec["flow_mean"][2 * k + 1] == fm[2 * k] and rec["flow_var"][2 * k + 1] == fv[2 * k], (name, seed)   # both entry points agree
+        if rec["reserved"][2 * k + 1]:
+            r = reruns.setdefault(name, [0, 0, 0])
+            r[0] += 1
+            r[1] += bool(rec["reserved"][2 * k + 1] & 0x0F)      # the solver's criterion (singular equations / runaway flow)
+            r[2] += bool(rec["reserved"][2 * k + 1] & 0xF0)      # the border-sign criterion
+    print(f"[soak] {len(jobs)} pairs, {len(fam)} families: max |delta flow_mean| = {worst:.3g}; pairs re-run in the call (incl. the in-between "
+          f"pairs): {rerun_total}; re-run soak pairs per family [total, solver criterion, border-sign criterion] of {PER_FAMILY}: {reruns}")

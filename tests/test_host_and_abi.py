@@ -44,7 +44,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.avd_abi_version() == 2
+    assert L.avd_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():

@@ -13,14 +13,44 @@
  *     i = 2  the product of the two at one pixel
  *     i = 3  max(g11, g22) / (det + 1e-3)          norm of the regularised inverse
  *     i = 4  (|g11 h2| + |g12 h1| + |g22 h1| + |g12 h2|) / (det + 1e-3) / level width   cancellation in the numerators
- *     i = 6  max |f(x+1) - f(x)| inside a solver lane's four columns
- *     i = 5  fraction of pixels with max(|fx|, |fy|) > width / 8
+ *     i = 6  jump max_c |R0[c] - R1[c]| at top / left border pixels whose deciding flow component is nonzero and below 1e-10 (round 5, border_ind)
+ *     i = 5  the same with the threshold 1e-6
  *     i = 7  max |new flow - incoming flow| of an iteration (px of the level)
  */
 #include <stdio.h>
 #include "fb_tolerance_exp.c"
 
 static double* g_ind;          /* 8 doubles of the level being processed, or NULL */
+
+
+/* i = 6 / i = 5 (round 5): the SIGN of a tiny flow at the top / left border.  cv2's warp (FarnebackUpdateMatrices) is discontinuous there: at x = 0,
+ * dx = -tiny gives x1 = -1, "outside" (R0 alone), dx = +tiny gives x1 = 0, "inside" (average with R1); likewise dy at y = 0.  Where both frames are
+ * flat at the border the two branches agree, so the indicator is the jump: max over border pixels whose deciding component is
+ * below 1e-12 of max(|R1[0]|, |R1[1]|, |R0[c] - R1[c]| c = 2..4) (cv2's own running-sum residue can reach ~1e-13 px there, with either sign);
+ * i = 5: nonzero components (criterion: jump > 1e-6), i = 6: exactly zero ones, where cv2's may be +-residue (criterion: jump > 0.05 -- two
+ * different flat frames, whose zero flow is structural, stay below that).  Called on the flow every matrix update reads. */
+static void border_ind(const float* R0, const float* R1, const float* flow, int h, int w)
+{
+    if (!g_ind) return;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            if (x != 0 && y != 0) continue;
+            const float* f = flow + ((int64_t)y * w + x) * 2;
+            double d = 1e30;
+            if (x == 0) d = fmin(d, fabs((double)f[0]));
+            if (y == 0) d = fmin(d, fabs((double)f[1]));
+            if (d >= 1e-12) continue;
+            double nf = 0;
+            /* what the two branches disagree by: outside takes r2 = R0[0] / 2, r3 = R0[1] / 2, r4.. = R0[2..]; inside (R0[0] - b[0]) / 2, .., (R0[2] + b[2]) / 2 ..
+             * with b the sample of R1 = (for an all-but-zero deciding component) the top-left pixel of the warped position, clamped as the kernel gathers it */
+            const int x1 = imin(imax((int)floorf((float)x + f[0]), 0), w - 2), y1 = imin(imax((int)floorf((float)y + f[1]), 0), h - 2);
+            const float* a = R0 + ((int64_t)y * w + x) * 5; const float* b = R1 + ((int64_t)y1 * w + x1) * 5;
+            nf = fmax(fabs((double)b[0]), fabs((double)b[1]));
+            for (int c = 2; c < 5; c++) nf = fmax(nf, fabs((double)a[c] - (double)b[c]));
+            if (d == 0 && nf > g_ind[6]) g_ind[6] = nf;     /* exactly zero: cv2's may be +-residue */
+            if (d != 0 && nf > g_ind[5]) g_ind[5] = nf;     /* nonzero, below 1e-12 */
+        }
+}
 
 static void blur_ind(const float* R0, const float* R1, float* flow_, float* matM, int h, int w, int block_size, int update_matrices)
 {
@@ -35,7 +65,6 @@ static void blur_ind(const float* R0, const float* R1, float* flow_, float* matM
         s0 = matM + (int64_t)imin(y, h - 1) * w * 5;
         for (int x = 0; x < w * 5; x++) vs[x] += s0[x];
     }
-    int64_t big = 0;
     for (int y = 0; y < h; y++) {
         const float* a = matM + (int64_t)imin(y + m, h - 1) * w * 5;
         const float* b = matM + (int64_t)imax(y - m - 1, 0) * w * 5;
@@ -74,20 +103,10 @@ static void blur_ind(const float* R0, const float* R1, float* flow_, float* matM
                 if (fm * cc > g_ind[2]) g_ind[2] = fm * cc;
                 if (inv > g_ind[3]) g_ind[3] = inv;
                 if (nc > g_ind[4]) g_ind[4] = nc;
-                if (fm > 0.125) big++;
             }
         }
     }
     if (g_ind) {
-        g_ind[5] = fmax(g_ind[5], (double)big / ((double)w * h));
-        /* i = 6: roughness, max |f(x + 1) - f(x)| within aligned groups of four columns (what one solver lane holds) */
-        for (int y = 0; y < h; y++)
-            for (int x = 0; x + 1 < w; x++) {
-                if ((x & 3) == 3) continue;
-                const float* f = newflow + ((int64_t)y * w + x) * 2;
-                const double r = fmax(fabs((double)f[2] - f[0]), fabs((double)f[3] - f[1]));
-                if (r > g_ind[6]) g_ind[6] = r;
-            }
     }
     if (g_ind) {
         /* i = 7: the iteration's UPDATE, max |new flow - incoming flow| (px of this level) */
@@ -97,7 +116,7 @@ static void blur_ind(const float* R0, const float* R1, float* flow_, float* matM
         }
     }
     memcpy(flow_, newflow, sizeof(float) * (size_t)w * h * 2);
-    if (update_matrices) avdo_update_matrices(R0, R1, flow_, matM, h, w, 0, h);
+    if (update_matrices) { border_ind(R0, R1, flow_, h, w); avdo_update_matrices(R0, R1, flow_, matM, h, w, 0, h); }
     free(vs); free(vrow); free(newflow);
 }
 
@@ -129,8 +148,9 @@ static int fast_with_indicators(const uint8_t* prev, const uint8_t* next, int h,
             avdo_resize_linear_f32(blur, h, w, 1, I, height, width);
             avdo_poly_exp(I, height, width, poly_n, poly_sigma, R[i]);
         }
-        avdo_update_matrices(R[0], R[1], flow, M, height, width, 0, height);
         g_ind = ind + 8 * k;
+        if (prevFlow) border_ind(R[0], R[1], flow, height, width);     /* not on the coarsest level's zero flow: identical in cv2 */
+        avdo_update_matrices(R[0], R[1], flow, M, height, width, 0, height);
         for (int i = 0; i < iterations; i++) blur_ind(R[0], R[1], flow, M, height, width, winsize, i < iterations - 1);
         g_ind = 0;
         if (prevFlow) free(prevFlow);

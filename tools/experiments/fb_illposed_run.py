@@ -46,7 +46,7 @@ def run_pair(args):
     out = (C.c_double * 40)()
     _lib.exp_illposed(a.ctypes.data, b.ctypes.data, out, with_sens)
     o = list(out)
-    return {"family": name, "seed": seed, "D": o[0], "dmean": o[1], "dvar": o[6], "sens_pyr": o[2], "sens_flow": o[3], "mean": o[4], "var": o[5],
+    return {"family": name, "seed": seed, "identical": bool(np.array_equal(a, b)), "D": o[0], "dmean": o[1], "dvar": o[6], "sens_pyr": o[2], "sens_flow": o[3], "mean": o[4], "var": o[5],
             "ind": [o[8 + 8 * l: 8 + 8 * l + 8] for l in range(4)]}
 
 
