@@ -43,8 +43,35 @@ class ContextPool:
         ctx = self._take(device)
         try:
             yield ctx
-        finally:
+        except BaseException:
+            # the request failed on this context: before it goes back to the MOST recently used end of the warm list -- the next request's
+            # pick -- its stream is probed.  A device error is sticky on a HIP stream: such a context is closed and its slot given back (the
+            # pool creates a fresh one); an ordinary error (bad argument, unreadable file) leaves a healthy context, which is reused.
+            if self._healthy(ctx):
+                self._give(device, ctx)
+            else:
+                self._drop(device, ctx, "the borrower's call failed and the context's stream reports an error")
+            raise
+        else:
             self._give(device, ctx)
+
+    @staticmethod
+    def _healthy(ctx) -> bool:
+        try:
+            ctx.synchronize()
+            return True
+        except Exception:
+            return False
+
+    def _drop(self, device, ctx, why):
+        logging.getLogger("avd_hip").warning("context dropped from the pool: %s", why)
+        try:
+            ctx.close()
+        except Exception:
+            pass
+        with self._cv:
+            self._count[device] = max(0, self._count.get(device, 0) - 1)
+            self._cv.notify()
 
     def _take(self, device):
         with self._cv:
@@ -81,14 +108,7 @@ class ContextPool:
             except Exception as exc:                       # must not mask the request's own result (or exception) ...
                 # ... but a context whose stream reports an error (sticky after a fault) must not be handed to the next request: it is
                 # logged, closed and its slot given back, so the pool creates a fresh one instead
-                logging.getLogger("avd_hip").warning("context dropped from the pool: release_workspace failed: %r", exc)
-                try:
-                    c.close()
-                except Exception:
-                    pass
-                with self._cv:
-                    self._count[device] = max(0, self._count.get(device, 0) - 1)
-                    self._cv.notify()
+                self._drop(device, c, "release_workspace failed: %r" % (exc,))
                 continue
             with self._cv:
                 self._cold.setdefault(device, []).append(c)

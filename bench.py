@@ -39,6 +39,7 @@ Prints ONE JSON line on rank 0.  What is measured, and how:
 """
 import argparse
 import json
+import math
 import os
 import statistics
 import sys
@@ -228,6 +229,12 @@ def compact_line(full, details_path=None):
     if full.get("fb_modes"):
         line["fb_modes"] = pick(full["fb_modes"], ("value_uses", "rerun_pairs", "guarantee", "exact_frames_per_s", "fast_without_rerun_frames_per_s",
                                                    "exact_level320_ms"))
+        rc = full["fb_modes"].get("rerun_cost")
+        if rc:
+            line["fb_modes"]["rerun_cost"] = {"unflagged_sec_per_video_resident": rc.get("unflagged_sec_per_video_resident"),
+                                              "exact_mode_sec_per_video_resident": rc.get("exact_mode_sec_per_video_resident"),
+                                              "exact_mode_frames_per_s": rc.get("exact_mode_frames_per_s"),
+                                              "cases": [pick(c, ("pairs_flagged", "sec_per_video_resident", "added_ms", "frames_per_s")) for c in rc["cases"]]}
     ext = {}
     for key, short in (("mfma_patch_embed", "patch_embed"), ("mfma_cnn_forward", "cnn_forward"), ("layernorm_tokens", "layernorm"),
                        ("roofline_nv12_ingest", "nv12_ingest")):
@@ -772,6 +779,64 @@ def main():
             c.close()
         del ectx
 
+    # ---- what the exact re-run of flagged pairs costs (default mode): the bench clip with 1 / 12 / all of its pairs replaced by content the level
+    # kernels flag (vertical sinusoid stripes: 1-D structure, the normal equations are singular) -- latency of the clip alone and throughput with
+    # clips in flight, beside the unflagged clip and fb_mode = exact.  The bench clip itself flags nothing (fb_modes.rerun_pairs).
+    rerun_cost = None
+    if not args.no_extras and world == 1 and ctxs[0].get_option("fb_mode") == 1 and ctxs[0].get_option("fb_rerun"):
+        xs = torch.arange(w, device=dev, dtype=torch.float32)
+
+        def stripe_frame(phase):
+            row = (127.0 + 120.0 * torch.sin((xs + phase) * (2.0 * math.pi / 60.0))).round().clamp(0, 255).to(torch.uint8)
+            return row[None, :, None].expand(h, w, 3)
+
+        def variant(pairs):
+            """frames[0] with `pairs` of its consecutive pairs made of stripe frames"""
+            v = frames[0].clone()
+            if pairs >= n - 1:
+                idx = list(range(n))
+            else:
+                stride = max(3, (n - 2) // pairs)
+                idx = [f for j in range(pairs) for f in (1 + j * stride, 2 + j * stride)]
+            for f in idx:
+                v[f] = stripe_frame(7.0 * f)
+            return v
+
+        rerun_cost = {"content": "vertical sinusoid stripes (period 60 px at 1080p) in place of the frames of 1 / 12 / all pairs of the bench clip",
+                      "unflagged_sec_per_video_resident": round(latency_ms / 1e3, 6), "cases": []}
+        rrec = [np.zeros(n, avd_hip.RECORD_DTYPE) for _ in range(m)]
+        for pairs in (1, 12, n - 1):
+            v = variant(pairs)
+            for _ in range(2):
+                ctxs[0].analyze_frames_async(v, rrec[0]); ctxs[0].synchronize()
+            flagged = ctxs[0].get_option("rerun_pairs")
+            ll = []
+            for _ in range(7):
+                t1 = time.perf_counter()
+                ctxs[0].analyze_frames_async(v, rrec[0]); ctxs[0].synchronize()
+                records_to_result(rrec[0], h * w, w, h, meta["fps"], meta["duration"])
+                ll.append(time.perf_counter() - t1)
+            thr = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                q = []
+                for i in range(args.steps):
+                    if len(q) == m:
+                        ctxs[q.pop(0)].synchronize()
+                    j = i % m
+                    ctxs[j].analyze_frames_async(v, rrec[j]); q.append(j)
+                while q:
+                    ctxs[q.pop(0)].synchronize()
+                thr.append(args.steps * n / (time.perf_counter() - t1))
+            lm = statistics.median(ll) * 1e3
+            rerun_cost["cases"].append({"pairs_replaced": pairs, "pairs_flagged": int(flagged), "sec_per_video_resident": round(lm / 1e3, 6),
+                                        "added_ms": round(lm - latency_ms, 4), "frames_per_s": round(statistics.median(thr), 1)})
+            del v
+        if exact is not None:
+            rerun_cost["exact_mode_sec_per_video_resident"] = round(exact["latency_ms"] / 1e3, 6)
+            rerun_cost["exact_mode_frames_per_s"] = round(exact["fps"], 1)
+
     # ---- batches: configs[0]-sized short clips and a configs[4] mixed-resolution stream (avd_analyze_batch)
     batches = None
     if not args.no_extras and world == 1:
@@ -1000,10 +1065,12 @@ def main():
             edom, _, efb = roofline_objects(n, h, w, exact["stage"], exact["latency_ms"], "exact", ops)
             out["fb_modes"] = {
                 "value_uses": fb_mode_used, "rerun_pairs": rerun_pairs,
-                "guarantee": "flagged (ill-posed) pairs re-run by the exact kernels: bit-identical; others flow <= 1e-5 px, flow_mean/var rel 1e-6, "
-                             "ai_susp 1e-6 (tests/test_gpu_fbfast.py, tests/test_gpu_soak.py)",
+                "guarantee": "pairs flagged by the level kernels (singular normal equations; sign of a residue-sized flow at the top / left border) re-run by the "
+                             "exact kernels: bit-identical; others flow <= 1e-5 px, flow_mean/var rel 1e-6, ai_susp 1e-6 -- no content family excepted "
+                             "(tests/test_gpu_fbfast.py, tests/test_gpu_soak.py: 28 families)",
                 "exact_frames_per_s": round(exact["fps"], 2), "exact_level320_ms": round(float(exact["stage"][4]), 4),
-                "fast": {"what": "csrc/avd_fbfast.hip + k_fb_rerun: flow identical to the oracle on well-posed inputs (<= 1e-5 px), ill-posed pairs re-run exactly",
+                "rerun_cost": rerun_cost,
+                "fast": {"what": "csrc/avd_fbfast.hip + exact re-run of flagged pairs (host-driven, compacted list): flow identical to the oracle on well-posed inputs (<= 1e-5 px), ill-posed pairs re-run exactly",
                          "frames_per_s": out["value"], "sec_per_video_resident": round(latency_ms / 1e3, 6),
                          "level0_all_iterations_ms": round(float(excl[4]), 4), "farneback_and_flow_stats_ms": round(float(excl[2]), 4),
                          "flow_mean_head": [float(v) for v in recs[0]["flow_mean"][1:4]]},

@@ -158,6 +158,9 @@ class _FakeCtx:
     def release_workspace(self):
         self.released += 1
 
+    def synchronize(self):
+        pass
+
     def close(self):
         self.closed = True
 
@@ -235,4 +238,36 @@ def test_context_pool_drops_a_context_whose_release_fails(monkeypatch, caplog):
     assert sum(c.closed for c in (a, b)) == 1 and "release_workspace failed" in caplog.text
     with pool.borrow(0) as c1, pool.borrow(0) as c2:                       # a fresh one can be created again
         assert not c1.closed and not c2.closed
+    pool.close()
+
+
+def test_context_pool_drops_the_context_whose_own_call_faulted(monkeypatch, caplog):
+    """The realistic path of a device fault: the BORROWER's call raises and the context's stream keeps reporting the (sticky) error.  That
+    context must not go back to the most-recently-used end of the warm list, where the next request would pick it: it is probed, closed and its
+    slot returned.  An ordinary failure of the request (bad argument) leaves a healthy context, which is reused."""
+    from avd_hip import analyzer
+
+    class Faulty(_FakeCtx):
+        sick = False
+
+        def synchronize(self):
+            if self.sick:
+                raise analyzer._lib.AvdError("hipStreamSynchronize: an illegal memory access was encountered")
+
+    monkeypatch.setattr(analyzer._lib, "Context", Faulty)
+    Faulty.made = 0
+    pool = analyzer.ContextPool(max_contexts=2, keep_warm=2)
+    with caplog.at_level("WARNING", logger="avd_hip"):
+        with pytest.raises(analyzer._lib.AvdError):
+            with pool.borrow(0) as a:
+                a.sick = True
+                raise analyzer._lib.AvdError("avd status -2: hipLaunchKernel: an illegal memory access was encountered")
+    assert a.closed and pool.stats(0) == {"created": 0, "warm": 0, "cold": 0} and "dropped from the pool" in caplog.text
+    with pytest.raises(ValueError):
+        with pool.borrow(0) as b:                                          # a fresh context, whose request fails for an ordinary reason
+            assert b is not a
+            raise ValueError("frames must be uint8[N,H,W,3] (BGR)")
+    assert not b.closed and pool.stats(0) == {"created": 1, "warm": 1, "cold": 0}
+    with pool.borrow(0) as c:
+        assert c is b                                                      # healthy: reused
     pool.close()
