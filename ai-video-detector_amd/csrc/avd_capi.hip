@@ -443,6 +443,7 @@ static int impl_create(int device_id, avd_ctx** out)
         if (const char* e = std::getenv("AVD_FB_FOLD_BLUR")) ctx->fb_fold_blur = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
         if (const char* e = std::getenv("AVD_FB_RERUN")) ctx->fb_rerun = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVD_GEMM_WAVES")) ctx->gemm_waves = std::atoi(e) == 16 ? 16 : 8;
         build_fb_consts(ctx->fbc);
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
              hipMemcpy(ctx->d_fbc, &ctx->fbc, sizeof(FbConsts), hipMemcpyHostToDevice) == hipSuccess;
@@ -905,6 +906,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_rerun_fused") == 0) { ctx->fb_rerun_fused = (value & 0xF) | 8; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value != 0; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { ctx->fb_fold_blur = value != 0; return AVD_OK; }
+    if (std::strcmp(name, "gemm_waves") == 0) { ctx->gemm_waves = value == 16 ? 16 : 8; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }
     if (std::strcmp(name, "cnn_fuse") == 0) { ctx->cnn_fuse = value < 0 ? 0 : (value > 2 ? 2 : value); return AVD_OK; }
     if (std::strcmp(name, "cnn_chunk") == 0) {
@@ -928,6 +930,7 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_rerun_fused") == 0) { *value = ctx->fb_rerun_fused; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { *value = ctx->fb_wide160; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { *value = ctx->fb_fold_blur; return AVD_OK; }
+    if (std::strcmp(name, "gemm_waves") == 0) { *value = ctx->gemm_waves; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { *value = ctx->cnn_tiles; return AVD_OK; }
     if (std::strcmp(name, "cnn_fuse") == 0) { *value = ctx->cnn_fuse; return AVD_OK; }
     if (std::strcmp(name, "cnn_chunk") == 0) { *value = ctx->cnn_chunk; return AVD_OK; }

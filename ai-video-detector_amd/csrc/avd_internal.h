@@ -186,6 +186,7 @@ struct avd_ctx {
     int cnn_tiles = 0;              // convolution tiling of the CNN extension: 0 = heuristic, 1 = 256-pixel tiles, 2 = 128 x 128 wherever possible
     int fb_fold_blur = 1;           // the 320-px scale's 3 x 3 pyramid blur formed inside the polynomial expansion (no effect on results); AVD_FB_FOLD_BLUR / avd_set_option
     int fb_wide160 = 1;             // fast mode: the 160-px level as one three-block strip per pair (fewer CU-microseconds: throughput) instead of two strips (shorter launches: latency); AVD_FB_WIDE160 / avd_set_option
+    int gemm_waves = 8;             // patch-embed GEMM: waves per workgroup (8: 8 x 4 MFMA tiles per wave, 16: 4 x 4; measured no faster), the same 256 x 256 tile; AVD_GEMM_WAVES / avd_set_option
     int cnn_chunk = 128;            // CNN extension: frames per forward pass (activation scratch = 4 x 1.6 MB per frame)
     int cnn_fuse = 2;               // CNN extension: a block's 3x3 and expanding 1x1 in one launch (stages 1, 2): 2 = with the 3x3's input slab in LDS in the stride-1 blocks (k_slab3_expand), 1 = gathering kernels only, 0 = layer by layer
     int fb_fused = 0xF;             // bit k: pyramid level k runs the fused kernel (avd_fbfused.hip) instead of k_uv/k_uvp + k_hscan

@@ -84,11 +84,16 @@ __global__ __launch_bounds__(256) void k_vit_patchify(const uint8_t* __restrict_
 // Tile order: logical workgroup id = (blockIdx % 8) * (grid / 8) + blockIdx / 8 and tile = id + i * grid: the column
 // tiles of one row block of A run at the same time on one XCD.
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES_M, int TI, int TJ>
+// NW waves per workgroup: 8 (round 2: a wave owns 8 x 4 MFMA tiles) or 16 (round 5: 4 x 4 tiles).  What a CU ingests through LDS-DMA is set by
+// how many WAVES issue it, not by the bytes in flight (tools/ldsdma_occ_bench.hip: 31-35 / 60-72 / 92-99 GB/s per CU from L2 with 4 / 8 / 16
+// waves, 2 to 18 KiB in flight per wave alike) -- so the operand stream of the same 256 x 256 tile runs half as long with sixteen waves.
+template <int WAVES_M, int TI, int TJ, int NW = 8, bool SKEW_ = true>
 struct TileShape {
-    static constexpr int WAVES_N = 8 / WAVES_M, TI_ = TI, TJ_ = TJ;
+    static constexpr int NWAVES = NW;
+    static constexpr bool SKEW = SKEW_;                         // half of each SIMD's waves run half a step late (see the kernel)
+    static constexpr int WAVES_N = NW / WAVES_M, TI_ = TI, TJ_ = TJ;
     static constexpr int BM = WAVES_M * TI * 16, BN = WAVES_N * TJ * 16;
-    static constexpr int RA = BM / 8, RB = BN / 8;              // rows of each operand that one wave stages per half stage
+    static constexpr int RA = BM / NW, RB = BN / NW;            // rows of each operand that one wave stages per half stage
     static_assert(RA % 8 == 0 && RB % 8 == 0 && TI % 2 == 0, "a wave stages whole or half LDS-DMA instructions (16 / 8 rows)");
     static constexpr int QA = (RA + 15) / 16, QB = (RB + 15) / 16;   // LDS-DMA instructions (the last one may be half masked)
     static constexpr int P = QA + QB;                           // ... per wave and half stage
@@ -132,7 +137,7 @@ __device__ __forceinline__ void stage_offsets(unsigned (&voff)[(R + 15) / 16], i
 #define AVD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <int K, int OUT_BF16, class T, int DBG = 0>
-__global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bt,
+__global__ __launch_bounds__(64 * T::NWAVES) void k_gemm_bf16_nt_persistent(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bt,
                                                                 const float* __restrict__ bias, void* __restrict__ Cv, int M, int N_)
 {
     constexpr int N = K;                                   // square weight (the patch embedding): offsets fold into immediates
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
     const int lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (lw >= total) return;
     float* lbias = reinterpret_cast<float*>(lds + T::LDS);
-    for (int i = threadIdx.x; i < N; i += 512) lbias[i] = bias ? bias[i] : 0.f;
+    for (int i = threadIdx.x; i < N; i += 64 * T::NWAVES) lbias[i] = bias ? bias[i] : 0.f;
 
     f32x4 acc[TI][TJ];
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -245,6 +250,23 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
 #pragma unroll
                 for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         };
+        // sixteen-wave shape without the half-step skew: four waves per SIMD hide each other's LDS latency, so a wave reads its A fragments
+        // one MFMA row ahead instead of all at once (128 registers per wave: the accumulators take 64 of them)
+        auto read_multiply = [&](int hs) __attribute__((always_inline)) {
+            if (DBG & 10) { read_frags(hs); multiply(); return; }      // timing experiments go through the separately switchable halves
+            const char* cur = lds + (hs % kStages) * T::STAGE;
+            const int chunk = lane >> 4, r16 = lane & 15;
+#pragma unroll
+            for (int j = 0; j < TJ; j++) b[j] = frag(cur + T::HALF_A, b_row(j, r16), chunk);
+            bf16x8 an = frag(cur, (wm * TI) * 16 + r16, chunk);
+#pragma unroll
+            for (int i = 0; i < TI; i++) {
+                const bf16x8 ac = an;
+                if (i + 1 < TI) an = frag(cur, (wm * TI + i + 1) * 16 + r16, chunk);
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], ac, acc[i][j], 0, 0, 0);
+            }
+        };
         int tile = lw;
         int m0 = (tile / tiles_n) * T::BM, n0 = (tile % tiles_n) * T::BN;
         int pm0 = m0, pn0 = n0;                              // late waves: the tile whose last fragments are still to be multiplied
@@ -284,7 +306,10 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
                     if (hs + kStages - 1 < NH) issue(m0, n0, hs + kStages - 1, (hs + kStages - 1) % kStages);
                     else if (more) issue(m1, n1, hs + kStages - 1 - NH, (hs + kStages - 1) % kStages);
                 };
-                if (!LATE) {
+                if (!LATE && !T::SKEW) {
+                    refill();
+                    read_multiply(hs);
+                } else if (!LATE) {
                     refill();
                     read_frags(hs);
                     __builtin_amdgcn_sched_barrier(0);      // all reads are issued before the first MFMA
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_nt_persistent(const uint16_t*
             store_tile(pm0, pn0);
         }
     };
-    if (wave >= 4) run(std::true_type{});
+    if (T::SKEW && ((wave >> 2) & 1)) run(std::true_type{});              // waves w, w + 4 (, w + 8, w + 12) share a SIMD: half of each SIMD's waves run late
     else run(std::false_type{});
 }
 
@@ -345,9 +370,9 @@ int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt,
 {
     if (M <= 0) return 0;
     if (N != kDim || K != kDim) { ctx->err = "gemm_bf16_nt: built for N = K = 768 (the ViT-B/16 patch embedding)"; return AVD_ERR_ARG; }
-    auto go = [&](auto kern, int grid, size_t lds, auto... args) -> int {
+    auto go = [&](auto kern, int threads, int grid, size_t lds, auto... args) -> int {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, args...);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, args...);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
@@ -362,17 +387,29 @@ int launch_gemm_bf16_nt(avd_ctx* ctx, const uint16_t* d_a, const uint16_t* d_bt,
         if (grid_sq > (tiles + 7) / 8 * 8) grid_sq = (tiles + 7) / 8 * 8;
         const size_t lds = (size_t)Sq::LDS + (size_t)N * sizeof(float);
 #ifdef AVD_GEMM_DEBUG
-        // timing experiments (tools/gemm_dbg.sh): AVD_GEMM_DBG bits 1 = no LDS-DMA, 2 = no MFMA, 4 = no stores, 8 = no fragment reads
+        // timing experiments (tools/gemm_dbg.sh, tools/r05_gemm_dbg.sh): AVD_GEMM_DBG bits 1 = no LDS-DMA, 2 = no MFMA, 4 = no stores, 8 = no fragment reads
         static const int dbg = [] { const char* e = std::getenv("AVD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();
+        using Dbg16 = TileShape<4, 4, 4, 16, false>;
         switch (dbg) {
-#define AVD_DBG_CASE(D) case D: return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq, D>, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+#define AVD_DBG_CASE(D) case D: if (ctx->gemm_waves == 16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Dbg16, D>, 1024, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N); \
+                                return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq, D>, 512, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
             AVD_DBG_CASE(1) AVD_DBG_CASE(2) AVD_DBG_CASE(4) AVD_DBG_CASE(8) AVD_DBG_CASE(3) AVD_DBG_CASE(5) AVD_DBG_CASE(6) AVD_DBG_CASE(7)
-            AVD_DBG_CASE(9) AVD_DBG_CASE(10) AVD_DBG_CASE(11) AVD_DBG_CASE(13) AVD_DBG_CASE(14) AVD_DBG_CASE(15) AVD_DBG_CASE(12)
+            AVD_DBG_CASE(10) AVD_DBG_CASE(12) AVD_DBG_CASE(14)
 #undef AVD_DBG_CASE
         default: break;
         }
 #endif
-        if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq>, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
-        return go(k_gemm_bf16_nt_persistent<kDim, 0, Sq>, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+        // ctx->gemm_waves (option "gemm_waves", AVD_GEMM_WAVES): 8 (default) = eight waves of 8 x 4 MFMA tiles, half of them half a step late;
+        // 16 = the same tile on sixteen waves of 4 x 4 tiles, no skew (round 5: an operand stream that sixteen waves issue runs at 92-99 instead of
+        // 60-72 GB/s per CU in isolation, tools/ldsdma_occ_bench.hip -- measured no faster in the kernel, 0.268-0.276 against 0.252-0.267 ms:
+        // loads, MFMAs and stores of this kernel add up rather than overlap whichever waves issue them, profiles/r05_experiments.md section 3)
+        using Sq16 = TileShape<4, 4, 4, 16, false>;
+        static_assert(Sq16::BM == Sq::BM && Sq16::BN == Sq::BN && Sq16::LDS == Sq::LDS, "the same tile, ring and grid");
+        if (ctx->gemm_waves == 16) {
+            if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq16>, 1024, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+            return go(k_gemm_bf16_nt_persistent<kDim, 0, Sq16>, 1024, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+        }
+        if (out_bf16) return go(k_gemm_bf16_nt_persistent<kDim, 1, Sq>, 512, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
+        return go(k_gemm_bf16_nt_persistent<kDim, 0, Sq>, 512, grid_sq, lds, d_a, d_bt, d_bias, d_c, M, N);
     }
 }

@@ -104,3 +104,22 @@ def test_patch_embed_device_output_and_rows_not_multiple_of_tile(ctx):
     out16 = torch.zeros((7, 196, 768), dtype=torch.bfloat16, device="cuda:0")
     ctx.vit_patch_embed(torch.from_numpy(frames).to("cuda:0"), out=out16, bf16=True)
     assert np.array_equal(out16.float().cpu().numpy(), ctx.vit_patch_embed(frames, bf16=True)[0])
+
+
+@pytest.mark.gpu
+def test_gemm_wave_shapes_give_the_same_tokens(ctx):
+    """Option "gemm_waves": the 256 x 256 tile on eight waves of 8 x 4 MFMA tiles (default) or on sixteen waves of 4 x 4 (round 5's A/B of the
+    operand-ingest question, profiles/r05_experiments.md section 3).  Every output is the same chain of MFMAs over k in both: identical bits."""
+    frames = synth.random_frames(9, 120, 160, seed=4)                      # M = 1764 rows: tiles with and without padding rows
+    rng = np.random.default_rng(6)
+    ctx.vit_set_weights((rng.standard_normal((768, 768)) * 0.02).astype(np.float32), (rng.standard_normal(768) * 0.1).astype(np.float32))
+    assert ctx.get_option("gemm_waves") == 8
+    t8, _ = ctx.vit_patch_embed(frames)
+    b8, _ = ctx.vit_patch_embed(frames, bf16=True)
+    ctx.set_option("gemm_waves", 16)
+    try:
+        t16, _ = ctx.vit_patch_embed(frames)
+        b16, _ = ctx.vit_patch_embed(frames, bf16=True)
+    finally:
+        ctx.set_option("gemm_waves", 8)
+    assert np.array_equal(t8, t16) and np.array_equal(b8, b16) and np.isfinite(t8).all()

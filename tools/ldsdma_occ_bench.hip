@@ -34,6 +34,7 @@ double run(const char* src, size_t bytes, int shared_src, int cus, int wg_per_cu
 {
     const int pieces = 16384 / (wg_per_cu * waves) * 8;                     // the same bytes per CU in every configuration
     const size_t lds = (size_t)waves * DEPTH * 1024;
+    if (lds * wg_per_cu > 160 * 1024) return -1.;
     CHECK(hipFuncSetAttribute((const void*)k_fill<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;
     CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fill<DEPTH>, waves * 64, lds));
@@ -67,7 +68,7 @@ int main()
         const size_t bytes = pass == 0 ? sb : bb;
         printf("\n%s\n", pass == 0 ? "source: one 1.1 MiB buffer read by every workgroup (an XCD's L2)" : "source: 768 MiB streamed once (HBM)");
         printf("%-28s %10s %10s %10s %10s\n", "waves/WG x WG/CU", "2 KiB/wave", "4 KiB/wave", "9 KiB/wave", "18 KiB/wave");
-        const int shapes[][2] = {{8, 1}, {4, 1}, {4, 2}, {8, 2}, {4, 4}, {2, 4}, {2, 8}, {1, 8}, {16, 1}};
+        const int shapes[][2] = {{8, 1}, {4, 1}, {4, 2}, {8, 2}, {4, 4}, {2, 4}, {2, 8}, {1, 8}, {16, 1}, {12, 1}};
         for (auto& sh : shapes) {
             const int waves = sh[0], wpc = sh[1];
             double r[4] = {run<2>(src, bytes, pass == 0, cus, wpc, waves), run<4>(src, bytes, pass == 0, cus, wpc, waves),
