@@ -2,6 +2,7 @@
 // Host C++; every kernel lives in avd_preprocess.hip / avd_farneback.hip.
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include "avd_internal.h"
@@ -412,6 +413,10 @@ static void stage_mark(avd_ctx* ctx, int i)
     if (hipEventRecord(ctx->stage_ev[i], ctx->stream) == hipSuccess) ctx->stage_marks++;
 }
 
+// contexts of this process (any device) that hold an enqueued, not yet drained avd_analyze_* call: what "fb_wide160" = 2 decides by
+std::atomic<int> g_calls_in_flight{0};
+int avd_calls_in_flight() { return g_calls_in_flight.load(std::memory_order_relaxed); }
+
 // ---- entry-point bodies (wrapped by the extern "C" functions at the end of the file) -----------------
 static void impl_destroy(avd_ctx* ctx);
 static int impl_synchronize(avd_ctx* ctx);
@@ -439,7 +444,7 @@ static int impl_create(int device_id, avd_ctx** out)
             ctx->num_cus = prop.multiProcessorCount;
         if (const char* e = std::getenv("AVD_FB_FUSED")) ctx->fb_fused = (int)std::strtol(e, nullptr, 0) & 0xF;
         if (const char* e = std::getenv("AVD_FB_FOLD_UP")) ctx->fb_fold_up = std::atoi(e) & 7;
-        if (const char* e = std::getenv("AVD_FB_WIDE160")) ctx->fb_wide160 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVD_FB_WIDE160")) { const int v = std::atoi(e); ctx->fb_wide160 = v == 0 ? 0 : (v == 1 ? 1 : 2); }
         if (const char* e = std::getenv("AVD_FB_FOLD_BLUR")) ctx->fb_fold_blur = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
         if (const char* e = std::getenv("AVD_FB_RERUN")) ctx->fb_rerun = std::atoi(e) != 0;
@@ -458,6 +463,7 @@ static void impl_destroy(avd_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->counted_in_flight) { ctx->counted_in_flight = 0; g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
     comm_destroy(ctx);
     free_ws(ctx->ws);
     if (ctx->d_fbc) (void)hipFree(ctx->d_fbc);
@@ -662,6 +668,7 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
     // the whole call is done and it would not be asynchronous at all; avd_synchronize hands the records over
     HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pending_out = records; ctx->pending_n = n;
+    if (!ctx->counted_in_flight) { ctx->counted_in_flight = 1; g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
     kmark(ctx, AVD_K_COUNT);                               // end of the last region
     stage_mark(ctx, 4);
     ctx->last_n = n;
@@ -744,6 +751,10 @@ static int impl_preprocess_nv12(avd_ctx* ctx, const Nv12Arg& a, int mem, int n, 
 static int impl_synchronize(avd_ctx* ctx)
 {
     if (!ctx) return AVD_ERR_ARG;
+    struct Uncount {                                        // whatever happens below, the call is no longer in flight afterwards
+        avd_ctx* c;
+        ~Uncount() { if (c->counted_in_flight) { c->counted_in_flight = 0; g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); } }
+    } uncount{ctx};
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->tail.active) {
         // fast Farneback mode: the records of the call's last chunk carry the level kernels' flag words; the pairs they mark go through the
@@ -904,7 +915,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 7; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun_fused") == 0) { ctx->fb_rerun_fused = (value & 0xF) | 8; return AVD_OK; }
-    if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value != 0; return AVD_OK; }
+    if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value == 0 ? 0 : (value == 1 ? 1 : 2); return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { ctx->fb_fold_blur = value != 0; return AVD_OK; }
     if (std::strcmp(name, "gemm_waves") == 0) { ctx->gemm_waves = value == 16 ? 16 : 8; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { ctx->cnn_tiles = value; return AVD_OK; }

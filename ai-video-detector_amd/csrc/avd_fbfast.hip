@@ -602,12 +602,13 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
         launch_fast<FGeo<320, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, mag_out, flags, pairdiff, np, 2, 160, zero_first, mode);
         break;
     case 160:
-        // two shapes (ctx->fb_wide160, default 1): a pair as ONE strip of three blocks with the 320-px level's wave mix (119 workgroups of 12 waves,
+        // two shapes (ctx->fb_wide160; default 2 = chosen per call, see below): a pair as ONE strip of three blocks with the 320-px level's wave mix (119 workgroups of 12 waves,
         // 58 us per launch) or as two 80-column strips of 14 waves (238 workgroups, 48 us per launch).  The narrow shape finishes a launch sooner
         // (one clip alone: -25 us); the wide one costs fewer CU-microseconds (119 x 58 against 238 x 48: lanes 91 % instead of 73 % on image
         // columns, 14 halo columns per pair instead of 28) and that is what counts with clips in flight: +2.4 % frames/s.  The two differ in the
         // grouping of the solver's window sums (four columns per lane against two): bit-identical on well-posed content, like the 320-px level.
-        if (ctx->fb_wide160) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 160, zero_first, mode);
+        // 2 = choose per call: this call is being enqueued and not yet counted, so > 0 means SOMEBODY ELSE's kernels will share the chip with it
+        if (ctx->fb_wide160 == 1 || (ctx->fb_wide160 == 2 && avd_calls_in_flight() - ctx->counted_in_flight > 0)) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 160, zero_first, mode);
         else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 2, 80, zero_first, mode);
         break;
     case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 80, zero_first, mode); break;

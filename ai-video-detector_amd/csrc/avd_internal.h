@@ -185,7 +185,9 @@ struct avd_ctx {
     void* d_comm = nullptr; size_t comm_bytes = 0;     // device staging of the record exchange
     int cnn_tiles = 0;              // convolution tiling of the CNN extension: 0 = heuristic, 1 = 256-pixel tiles, 2 = 128 x 128 wherever possible
     int fb_fold_blur = 1;           // the 320-px scale's 3 x 3 pyramid blur formed inside the polynomial expansion (no effect on results); AVD_FB_FOLD_BLUR / avd_set_option
-    int fb_wide160 = 1;             // fast mode: the 160-px level as one three-block strip per pair (fewer CU-microseconds: throughput) instead of two strips (shorter launches: latency); AVD_FB_WIDE160 / avd_set_option
+    int fb_wide160 = 2;             // fast mode: the 160-px level as one three-block strip per pair (1: fewer CU-microseconds, throughput) or as two strips (0: shorter launches, latency);
+                                    // 2 (default) = by what is in flight when the call is enqueued: one strip if another context of the process holds an undrained call, two if this clip is alone; AVD_FB_WIDE160 / avd_set_option
+    int counted_in_flight = 0;      // this context's enqueued call is counted in avd_calls_in_flight()
     int gemm_waves = 8;             // patch-embed GEMM: waves per workgroup (8: 8 x 4 MFMA tiles per wave, 16: 4 x 4; measured no faster), the same 256 x 256 tile; AVD_GEMM_WAVES / avd_set_option
     int cnn_chunk = 128;            // CNN extension: frames per forward pass (activation scratch = 4 x 1.6 MB per frame)
     int cnn_fuse = 2;               // CNN extension: a block's 3x3 and expanding 1x1 in one launch (stages 1, 2): 2 = with the 3x3's input slab in LDS in the stride-1 blocks (k_slab3_expand), 1 = gathering kernels only, 0 = layer by layer
@@ -239,6 +241,7 @@ int launch_preprocess(avd_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w,
 int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& nv, int n, int h, int w,
                            int64_t row_stride, int64_t frame_stride);
 int launch_hash(avd_ctx* ctx, int n, bool with_hamming = true);
+int avd_calls_in_flight();      // avd_capi.hip: contexts of this process holding an enqueued, undrained avd_analyze_* call
 int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, int n, int frame_off, int pair_off);
 int launch_flow_stats(avd_ctx* ctx, hipStream_t stream, int n, int frame_off, int pair_off);
 // avd_vit.hip (extension): patchify + bf16 MFMA GEMM; all pointers device

@@ -121,9 +121,52 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ x, fl
     }
 }
 
+// ANY row length (round 5: the fast kernels above cover the shapes of the classifier stack; every other shape used to be refused): one wave per
+// row, lanes stride over the columns, the row is read from memory once per pass (sum; squared deviations; output -- L2 serves the re-reads).
+// The same float32 statistics in the same order per lane would not be bit-identical to the fast kernels (another grouping of the sums); both are
+// checked against float32 torch (tests/test_norm.py).
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_layernorm_any(const void* __restrict__ xin, void* __restrict__ yout, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, long long rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    auto at = [&](int c) -> float {
+        return BF16 ? bf16_to_f(static_cast<const unsigned short*>(xin)[row * cols + c]) : static_cast<const float*>(xin)[row * cols + c];
+    };
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += at(c);
+    const float mean = wave_sum_f(s) / (float)cols;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float d = at(c) - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum_f(q) / (float)cols + eps);
+    for (int c = lane; c < cols; c += 64) {
+        const float o = (at(c) - mean) * rstd * gamma[c] + beta[c];
+        if (BF16) static_cast<unsigned short*>(yout)[row * cols + c] = f_to_bf16(o);
+        else static_cast<float*>(yout)[row * cols + c] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_softmax_any(const float* __restrict__ x, float* __restrict__ y, long long rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = x + row * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, src[c]);
+    m = wave_max_f(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += expf(src[c] - m);
+    const float inv = 1.f / wave_sum_f(s);
+    for (int c = lane; c < cols; c += 64) y[row * cols + c] = expf(src[c] - m) * inv;
+}
+
 }  // namespace
 
-// device pointers; x / y float32 or bf16 [rows][cols], gamma / beta float32 [cols]; cols = 256, 512, 768, 1024, 2048
+// device pointers; x / y float32 or bf16 [rows][cols], gamma / beta float32 [cols]; cols = 256, 512, 768, 1024, 2048 run the register-resident
+// kernel, any other cols >= 1 the general one
 int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps)
 {
     if (rows <= 0) return 0;
@@ -139,7 +182,10 @@ int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long lo
     case 768: AVD_LN_CASE(3); break;
     case 1024: AVD_LN_CASE(4); break;
     case 2048: AVD_LN_CASE(8); break;
-    default: ctx->err = "avd_layernorm: cols must be 256, 512, 768, 1024 or 2048"; return AVD_ERR_UNSUPPORTED;
+    default:
+        if (cols < 1) { ctx->err = "avd_layernorm: cols must be positive"; return AVD_ERR_ARG; }
+        if (bf16) hipLaunchKernelGGL(k_layernorm_any<true>, grid, block, 0, ctx->stream, d_x, d_y, d_gamma, d_beta, eps, rows, cols);
+        else hipLaunchKernelGGL(k_layernorm_any<false>, grid, block, 0, ctx->stream, d_x, d_y, d_gamma, d_beta, eps, rows, cols);
     }
 #undef AVD_LN_CASE
     HIP_TRY(ctx, hipGetLastError());
@@ -149,10 +195,12 @@ int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long lo
 int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols)
 {
     if (rows <= 0) return 0;
-    if (cols < 4 || (cols & 3) || cols > 4096) { ctx->err = "avd_softmax: cols must be a multiple of 4 in 4..4096"; return AVD_ERR_UNSUPPORTED; }
+    if (cols < 1) { ctx->err = "avd_softmax: cols must be positive"; return AVD_ERR_ARG; }
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const int p = (cols / 4 + 63) / 64;
-    if (p <= 4) hipLaunchKernelGGL(k_softmax<4>, grid, block, 0, ctx->stream, d_x, d_y, rows, cols);
+    // rows of whole float4s up to 4096 logits stay in registers; any other length goes through the general kernel
+    if ((cols & 3) || cols > 4096) hipLaunchKernelGGL(k_softmax_any, grid, block, 0, ctx->stream, d_x, d_y, rows, cols);
+    else if (p <= 4) hipLaunchKernelGGL(k_softmax<4>, grid, block, 0, ctx->stream, d_x, d_y, rows, cols);
     else if (p <= 8) hipLaunchKernelGGL(k_softmax<8>, grid, block, 0, ctx->stream, d_x, d_y, rows, cols);
     else hipLaunchKernelGGL(k_softmax<16>, grid, block, 0, ctx->stream, d_x, d_y, rows, cols);
     HIP_TRY(ctx, hipGetLastError());

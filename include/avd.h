@@ -285,9 +285,11 @@ int avd_set_profiling(avd_ctx* ctx, int enable);
  * "fb_fold_blur" (default 1, environment AVD_FB_FOLD_BLUR; no effect on results): the 3 x 3 Gaussian of the 320-px pyramid scale is formed inside
  * the polynomial expansion (same two float passes, same operation order) instead of being written by the pyramid kernel and read back;
  * avd_debug_fetch "pyr0" exists with the option off only (an error otherwise: the buffer is not even allocated).
- * "fb_wide160" (fast mode, default 1, environment AVD_FB_WIDE160): the 160-px level runs a pair as ONE strip of three 64-column blocks
- * (119 workgroups, fewer CU-microseconds: +2.4 % frames/s with clips in flight) instead of two 80-column strips (238 workgroups, each
- * launch 10 us shorter: one clip alone finishes ~25 us sooner).  Same guarantee; the two shapes group the solver's window sums differently.
+ * "fb_wide160" (fast mode, environment AVD_FB_WIDE160): 1 = the 160-px level runs a pair as ONE strip of three 64-column blocks
+ * (119 workgroups, fewer CU-microseconds: +2.4 % frames/s with clips in flight), 0 = as two 80-column strips (238 workgroups, each
+ * launch 10 us shorter: one clip alone finishes ~25 us sooner), 2 (default) = chosen when the call is enqueued: one strip if another context of the
+ * process holds an undrained avd_analyze_* call, two strips if this clip has the chip to itself.  Same guarantee; the two shapes group the solver's
+ * window sums differently (bit-identical on well-posed content, tests/test_gpu_fbfast.py).
  * "fb_fused" (exact mode only, no effect on results): bit k set = pyramid level k (0 = 320x320 .. 3 = 40x40)
  * of the Farneback stage runs the fused level kernel (default 0xF, or the environment variable AVD_FB_FUSED at
  * avd_create); clear = the two-kernel path that exchanges its double intermediate through HBM.  "cnn_tiles": tiling of the

@@ -164,7 +164,7 @@ def test_the_printed_line_is_compact_and_keeps_what_the_driver_reads():
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     r = line["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert r["bound"] in ("hbm", "mfma", "valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     assert r["traffic_from_profiles"] and r["valu_issue_frac_from_profiles"] == 0.55 and r["ta_busy_frac_from_profiles"] == 0.53
     names = [k["name"] for k in r["kernels"]]
     for want in ("preprocess", "pyramid", "polyexp", "level40", "level80", "level160", "level320", "stats"):

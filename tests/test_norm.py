@@ -9,7 +9,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("rows,cols", [(5, 768), (196 * 3, 768), (7, 256), (9, 2048), (1, 1024)])
+@pytest.mark.parametrize("rows,cols", [(5, 768), (196 * 3, 768), (7, 256), (9, 2048), (1, 1024), (7, 33), (3, 1), (4, 1000), (2, 5000)])   # the last four: the general kernel (any row length)
 def test_layernorm_f32_against_torch(ctx, rows, cols):
     rng = np.random.default_rng(rows + cols)
     x = (rng.standard_normal((rows, cols)) * 3 + rng.standard_normal((rows, 1)) * 5).astype(np.float32)
@@ -41,11 +41,11 @@ def test_layernorm_bf16_tokens(ctx):
         ctx.layernorm(np.zeros((2, 100), np.float32), np.ones(100, np.float32), np.zeros(100, np.float32))
 
 
-@pytest.mark.parametrize("rows,cols", [(120, 1000), (3, 4), (5, 4096), (2, 1024)])
+@pytest.mark.parametrize("rows,cols", [(120, 1000), (3, 4), (5, 4096), (2, 1024), (7, 33), (3, 1), (2, 4100), (5, 1001)])   # the last four: the general kernel
 def test_softmax_against_torch(ctx, rows, cols):
     rng = np.random.default_rng(cols)
     x = (rng.standard_normal((rows, cols)) * 6).astype(np.float32)
-    x[0, :3] = [80.0, -90.0, 79.5]                                  # large logits: the max subtraction matters
+    x[0, :min(3, cols)] = [80.0, -90.0, 79.5][:cols]                # large logits: the max subtraction matters
     want = torch.softmax(torch.from_numpy(x), dim=1).numpy()
     got, _ = ctx.softmax(x)
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
