@@ -516,20 +516,25 @@ __host__ __device__ constexpr int d16_pair_tiles(int w) { return (d16_nyb(w) * 5
 // around memory operations.  50 KiB of LDS = 3 workgroups per CU by LDS, 2 by registers (6 waves x 104 VGPRs).
 // ---------------------------------------------------------------------------------------
 template <int W, int NPROD>
-__global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
+__global__ __launch_bounds__(64 * (NPROD + 2), (NPROD <= 4 ? 4 : 1)) void k_uvp(const float* __restrict__ R, const float* __restrict__ flow,
                                                            double* __restrict__ D16, double* __restrict__ VS0, int npairs, const int* __restrict__ plist)
 {
-    static_assert(NPROD >= 2 && NPROD <= 4 && 24 % NPROD == 0, "ring size below covers 2 to 4 producers");
+    // NPROD = 2 .. 4: the throughput shapes (three workgroups per CU).  NPROD = 12 (round 5): the LATENCY shape of the exact re-run of a few
+    // flagged pairs -- a phase lasts about one memory round trip (the gather issued in phase k is consumed in phase k + 1) however many rows
+    // it brings in, so twelve producers walk a level's rows in a third of the phases (28 instead of 82 at 320 px); one 14-wave workgroup per CU.
+    static_assert((NPROD >= 2 && NPROD <= 4 && 24 % NPROD == 0) || NPROD == 8 || NPROD == 12, "ring size below covers these producer counts");
     constexpr int H = W, m = 7;
     constexpr int NSTRIP = (W + kStripW - 1) / kStripW, XCH = d16_xch(W);
     constexpr int plane = W * H;
-    constexpr int RSL = 24;                              // M-row ring in LDS: 15 rows of history + two phases in flight (producers write phase k+1
+    constexpr int RSL = NPROD <= 4 ? 24 : 4 * NPROD;     // M-row ring in LDS: 15 rows of history + two phases in flight (producers write phase k+1
                                                          // while the summer still reads the leaving rows of phase k); 20 would collide
+    static_assert(RSL % NPROD == 0 && RSL >= 15 + 2 * NPROD, "ring: whole phases, history + two phases in flight");
+    constexpr int CH = NPROD <= 4 ? NPROD : 4;           // entries the summer / storer hold in registers at a time
     constexpr int U = 4;                                 // phases per unrolled body (static producer register slots)
     constexpr int NE = H + m;                            // entries
     constexpr int NP = (NE + NPROD - 1) / NPROD;         // producing phases
     constexpr int NPH = ((NP + 2 + U - 1) / U) * U;      // loop trip count (two drain phases + round up to the unroll)
-    __shared__ float ringM[RSL][5][64];                  // normal-equation rows, slot = entry % RSL (30 KiB)
+    __shared__ float ringM[RSL][5][64];                  // normal-equation rows, slot = entry % RSL (30 KiB; 60 KiB with twelve producers)
     __shared__ double Vb[2][NPROD][5][64];               // vsum rows of a phase, summer -> storer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // workgroups are dealt round-robin to the 8 XCDs.  The strips of a pair share their halo columns and the
@@ -560,23 +565,26 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
                     }
                 }
                 // entering rows (this phase's entries) and the rows leaving the box with them (row y-8 = entry e-15;
-                // row 0 while the window still touches the top edge), all reads first
-                float a[NPROD][5], b[NPROD][5];
+                // row 0 while the window still touches the top edge), all reads of a chunk of entries first
 #pragma unroll
-                for (int i = 0; i < NPROD; i++) {
-                    const int e = e0 + i, y = e - m;
-                    const int sa = e % RSL, sb = y >= m + 1 ? (e - 15) % RSL : 0;
+                for (int c0 = 0; c0 < NPROD; c0 += CH) {
+                    float a[CH][5], b[CH][5];
 #pragma unroll
-                    for (int c = 0; c < 5; c++) { a[i][c] = ringM[sa][c][lane]; b[i][c] = ringM[sb][c][lane]; }
-                }
+                    for (int i = 0; i < CH; i++) {
+                        const int e = e0 + c0 + i, y = e - m;
+                        const int sa = e % RSL, sb = y >= m + 1 ? (e - 15) % RSL : 0;
 #pragma unroll
-                for (int i = 0; i < NPROD; i++) {
-                    const int e = e0 + i;
-                    if (e >= m && e < NE) {
+                        for (int c = 0; c < 5; c++) { a[i][c] = ringM[sa][c][lane]; b[i][c] = ringM[sb][c][lane]; }
+                    }
 #pragma unroll
-                        for (int c = 0; c < 5; c++) {
-                            vs[c] += (double)(a[i][c] - b[i][c]);
-                            Vb[pb][i][c][lane] = vs[c];
+                    for (int i = 0; i < CH; i++) {
+                        const int e = e0 + c0 + i;
+                        if (e >= m && e < NE) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) {
+                                vs[c] += (double)(a[i][c] - b[i][c]);
+                                Vb[pb][c0 + i][c][lane] = vs[c];
+                            }
                         }
                     }
                 }
@@ -597,24 +605,27 @@ __global__ __launch_bounds__(64 * (NPROD + 2), 4) void k_uvp(const float* __rest
         for (int k = 0; k < NPH; k++) {
             if (k >= 2 && k - 2 < NP) {
                 const int e0 = NPROD * (k - 2), pb = (k - 2) & 1;
-                double dv[NPROD][5];
 #pragma unroll
-                for (int i = 0; i < NPROD; i++)
+                for (int c0 = 0; c0 < NPROD; c0 += CH) {
+                    double dv[CH][5];
 #pragma unroll
-                    for (int c = 0; c < 5; c++) dv[i][c] = Vb[pb][i][c][lhi] - Vb[pb][i][c][llo];
+                    for (int i = 0; i < CH; i++)
 #pragma unroll
-                for (int i = 0; i < NPROD; i++) {
-                    const int e = e0 + i, y = e - m;
-                    if (e >= m && e < NE) {
-                        if (writer) {
-                            const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
-                            const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
+                        for (int c = 0; c < 5; c++) dv[i][c] = Vb[pb][c0 + i][c][lhi] - Vb[pb][c0 + i][c][llo];
 #pragma unroll
-                            for (int c = 0; c < 5; c++) st_off_nt<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, dv[i][c]);
-                        }
-                        if (head) {
+                    for (int i = 0; i < CH; i++) {
+                        const int e = e0 + c0 + i, y = e - m;
+                        if (e >= m && e < NE) {
+                            if (writer) {
+                                const unsigned sw = (unsigned)((x & 7) ^ (y & 7)) - (unsigned)(x & 7);     // swizzled slot - plain slot
+                                const unsigned t0 = dbase + ((unsigned)(y >> 6) * 5 * XCH) * 512u + (y & 63) * 8 + sw;
 #pragma unroll
-                            for (int c = 0; c < 5; c++) st_off<double>(VS0, (vbase + (unsigned)((c * H + y) * 8)) * 8u, Vb[pb][i][c][lane]);
+                                for (int c = 0; c < 5; c++) st_off_nt<double>(D16, (t0 + (unsigned)c * XCH * 512u) * 8u, dv[i][c]);
+                            }
+                            if (head) {
+#pragma unroll
+                                for (int c = 0; c < 5; c++) st_off<double>(VS0, (vbase + (unsigned)((c * H + y) * 8)) * 8u, Vb[pb][c0 + i][c][lane]);
+                            }
                         }
                     }
                 }
@@ -1114,7 +1125,17 @@ void blur_iteration(const Seg& g, int k, int np, float* flow, const int* plist)
     // at 320x320 the producer / consumer form wins as long as all its workgroups are resident at once (3 per CU,
     // 50 KiB of LDS each): ~170 us per launch instead of ~290 us; beyond that it needs a second residency round
     const bool uvp_fits = np * NSTRIP <= 3 * 256;
-    if (variant == 1 || (variant == 2 && (W < S || uvp_fits))) {
+    bool latency_shape = false;
+    if constexpr (W >= S / 2) {
+        // the exact re-run of a few flagged pairs (160 / 320 px): the latency shape (twelve producers: a third of the phases), one workgroup per CU
+        if (plist && np * NSTRIP <= 256) {
+            latency_shape = true;
+            hipLaunchKernelGGL((k_uvp<W, 12>), dim3(grid), dim3(64 * 14), 0, g.stream, (const float*)g.poly[k],
+                               (const float*)flow, g.vs, g.vs0, np, plist);
+        }
+    }
+    if (latency_shape) {
+    } else if (variant == 1 || (variant == 2 && (W < S || uvp_fits))) {
         hipLaunchKernelGGL((k_uvp<W, 4>), dim3(grid), dim3(384), 0, g.stream, (const float*)g.poly[k],
                            (const float*)flow, g.vs, g.vs0, np, plist);
     } else {

@@ -37,8 +37,14 @@ def test_layernorm_bf16_tokens(ctx):
     ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -126)) * 2.0 ** -7
     assert torch.all((got - want).abs() <= ulp + 1e-6), float(((got - want).abs() / ulp).max())
     assert torch.equal(got[5], torch.from_numpy(b).to(torch.bfloat16).float()) and ms > 0
-    with pytest.raises(Exception):
-        ctx.layernorm(np.zeros((2, 100), np.float32), np.ones(100, np.float32), np.zeros(100, np.float32))
+    # any other row length goes through the general kernel (round 4 refused it): bf16 tokens of 100 and 770 values
+    for c2 in (100, 770):
+        x2 = torch.from_numpy((rng.standard_normal((9, c2)) * 2).astype(np.float32)).to(torch.bfloat16)
+        g2, b2 = rng.standard_normal(c2).astype(np.float32), rng.standard_normal(c2).astype(np.float32)
+        want2 = torch.nn.functional.layer_norm(x2.float(), (c2,), torch.from_numpy(g2), torch.from_numpy(b2), 1e-5)
+        got2 = ctx.layernorm(x2.to("cuda:0"), g2, b2, 1e-5)[0].cpu().float()
+        ulp2 = torch.maximum(want2.abs(), torch.tensor(2.0 ** -126)) * 2.0 ** -7
+        assert torch.all((got2 - want2).abs() <= ulp2 + 1e-6), c2
 
 
 @pytest.mark.parametrize("rows,cols", [(120, 1000), (3, 4), (5, 4096), (2, 1024), (7, 33), (3, 1), (2, 4100), (5, 1001)])   # the last four: the general kernel
