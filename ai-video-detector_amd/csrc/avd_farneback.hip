@@ -937,6 +937,110 @@ __global__ __launch_bounds__(128) void k_hscan(const double* __restrict__ D16, c
 }
 
 // ---------------------------------------------------------------------------------------
+// k_hscan_lat: the same horizontal pass in a LATENCY shape, for the exact re-run of a few flagged pairs (round 5).  In k_hscan a lane owns a
+// row and walks its 320 columns alone: five dependent double adds AND the 2 x 2 solve with its IEEE division per column, ~115 ns per column,
+// 37 us per launch however few pairs there are.  Only the adds are a chain.  Here the scanner wave does nothing but the chain (g of a chunk of
+// eight columns goes to LDS), and four SOLVER waves one chunk behind turn g into flow -- 512 (row, column) solves per chunk, two per lane, the
+// same expressions in the same order as k_hscan (bit-identical) -- and store it through a 16-row transpose.  One barrier per chunk.
+// ---------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(384) void k_hscan_lat(const double* __restrict__ D16, const double* __restrict__ VS0,
+                                                  float* __restrict__ flow, int npairs, const int* __restrict__ plist)
+{
+    constexpr int H = W, m = 7;
+    constexpr int XCH = d16_xch(W), NYB = d16_nyb(H);
+    static_assert(XCH % 2 == 0, "the loader alternates two register sets");
+    constexpr int64_t plane = (int64_t)W * H;
+    constexpr int GS = 5 * 64 + 2;                        // doubles per column of a g buffer (+ 2: the four columns a solver instruction reads fall on different banks)
+    __shared__ __align__(16) double lds[2][5][512];
+    __shared__ __align__(16) double gbuf[2][8][GS];
+    __shared__ __align__(16) float outb[4][2][16][8];     // per solver wave: [component][row][column of the chunk]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ps = blockIdx.x / NYB, ybk = blockIdx.x - ps * NYB;
+    const int p = plist ? plist[ps] : ps;                // ps indexes the scratch, p the pair's flow
+    const double* tiles = D16 + ((int64_t)ps * d16_pair_tiles(W) + (int64_t)ybk * 5 * XCH) * 512;   // [c][xc][512]
+    if (wave == 1) {
+        // loader: chunk xc + 1 is committed to LDS while the scanner walks chunk xc; two chunks further are in flight
+        ChunkRegs ra, rb;
+        chunk_issue(ra, tiles, XCH, 0, lane);
+        chunk_issue(rb, tiles, XCH, 1, lane);
+        chunk_commit(ra, lds[0], lane);
+        __syncthreads();
+        for (int xc = 0; xc < XCH; xc += 2) {
+            if (xc + 2 < XCH) chunk_issue(ra, tiles, XCH, xc + 2, lane);
+            chunk_commit(rb, lds[1], lane);
+            __syncthreads();
+            if (xc + 3 < XCH) chunk_issue(rb, tiles, XCH, xc + 3, lane);
+            if (xc + 2 < XCH) chunk_commit(ra, lds[0], lane);
+            __syncthreads();
+        }
+        return;
+    }
+    if (wave == 0) {
+        // scanner: cv2's running sums g += D(x), literally; nothing else
+        const int yc = min(ybk * 64 + lane, H - 1);
+        double g[5];
+        const double* v0 = VS0 + ((int64_t)ps * 5 * H + yc) * 8;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double* vc = v0 + (int64_t)c * H * 8;
+            double s = vc[0] * (double)(m + 2);
+#pragma unroll
+            for (int k = 1; k < m; k++) s += vc[k];
+            g[c] = s;
+        }
+        __syncthreads();
+        const int sw = lane & 7;
+        for (int xc = 0; xc < XCH; xc++) {
+            const int buf = xc & 1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    g[c] += lds[buf][c][lane * 8 + (j ^ sw)];
+                    gbuf[buf][j][c * 64 + lane] = g[c];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // solvers: wave s owns rows 16 s .. 16 s + 15 of the block; lane = (row, column j) and (row, column j + 4) of the chunk
+    const int s4 = wave - 2, r16 = lane & 15, j0 = lane >> 4;
+    const int row = 16 * s4 + r16;
+    const double scale = 1. / (15 * 15);
+    float (*ob)[16][8] = outb[s4];
+    const int sr = (lane & 31) >> 1, sh = lane & 1, sc = lane >> 5;       // store phase: row, 16-byte half of the chunk's 32 bytes, component
+    const bool store_ok = ybk * 64 + 16 * s4 + sr < H;
+    float* fout = flow + (int64_t)p * 2 * plane + (int64_t)sc * plane + (int64_t)(ybk * 64 + 16 * s4 + sr) * W + sh * 4;
+    auto solve = [&](int xc) {
+        const int buf = xc & 1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int j = j0 + 4 * i;
+            const double* gp = &gbuf[buf][j][row];
+            const double g11 = gp[0] * scale, g12 = gp[64] * scale, g22 = gp[128] * scale;
+            const double h1 = gp[192] * scale, h2 = gp[256] * scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            ob[0][r16][j] = (float)((g11 * h2 - g12 * h1) * idet);
+            ob[1][r16][j] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (store_ok) *reinterpret_cast<float4*>(fout + xc * 8) = *reinterpret_cast<const float4*>(&ob[sc][sr][sh * 4]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    __syncthreads();
+    for (int xc = 0; xc < XCH; xc++) {
+        if (xc >= 1) solve(xc - 1);
+        __syncthreads();
+    }
+    solve(XCH - 1);
+}
+
+// ---------------------------------------------------------------------------------------
 // Flow statistics in numpy's float32 order (video.py:46-48): mag = sqrt(fx*fx + fy*fy);
 // add.reduce = pairwise sums (128-element leaves, 8 strided accumulators) inside 8192-element
 // iterator buffers whose results are added sequentially.  One workgroup per pair.
@@ -1143,6 +1247,14 @@ void blur_iteration(const Seg& g, int k, int np, float* flow, const int* plist)
                            (const float*)flow, g.vs, g.vs0, np, plist);
     }
     mark(); mark();
+    if constexpr (W >= S / 2) {
+        if (latency_shape) {
+            hipLaunchKernelGGL(k_hscan_lat<W>, dim3(np * d16_nyb(W)), dim3(384), 0, g.stream, (const double*)g.vs,
+                               (const double*)g.vs0, flow, np, plist);
+            mark();
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_hscan<W>, dim3(np * d16_nyb(W)), dim3(128), 0, g.stream, (const double*)g.vs,
                        (const double*)g.vs0, flow, np, plist);
     mark();
