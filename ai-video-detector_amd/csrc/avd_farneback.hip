@@ -530,7 +530,11 @@ __global__ __launch_bounds__(64 * (NPROD + 2), (NPROD <= 4 ? 4 : 1)) void k_uvp(
                                                          // while the summer still reads the leaving rows of phase k); 20 would collide
     static_assert(RSL % NPROD == 0 && RSL >= 15 + 2 * NPROD, "ring: whole phases, history + two phases in flight");
     constexpr int CH = NPROD <= 4 ? NPROD : 4;           // entries the summer / storer hold in registers at a time
-    constexpr int U = 4;                                 // phases per unrolled body (static producer register slots)
+    // gather lead in phases.  With four producers a phase is about one memory round trip and the gather of the next phase hides behind it.  With twelve, a
+    // phase is the CU's own work for twelve rows (~1.5 us of VALU + texture addresser) and a gather issued at its END would be waited for at the START of the next:
+    // it is issued TWO phases ahead, so the round trip overlaps a whole phase of work
+    constexpr int GL = NPROD >= 8 ? 2 : 1, GR = GL + 1;
+    constexpr int U = NPROD >= 8 ? 12 : 4;               // phases per unrolled body (static producer register slots: four input sets, GR gather sets)
     constexpr int NE = H + m;                            // entries
     constexpr int NP = (NE + NPROD - 1) / NPROD;         // producing phases
     constexpr int NPH = ((NP + 2 + U - 1) / U) * U;      // loop trip count (two drain phases + round up to the unroll)
@@ -638,11 +642,12 @@ __global__ __launch_bounds__(64 * (NPROD + 2), (NPROD <= 4 ? 4 : 1)) void k_uvp(
     // ----------------------------------- producers ------------------------------------------
     const unsigned r0base = (unsigned)p * 5u * plane, r1base = r0base + 5u * plane, flbase = (unsigned)p * 2u * plane;
     const int pi = wave - 2;                             // entry index inside a phase
-    NeIn in[4]; NeG g[2];
+    NeIn in[4]; NeG g[GR];
     auto row_of = [&](int k) { return min(NPROD * k + pi, H - 1); };
 #pragma unroll
     for (int k = 0; k < 3; k++) ne_load(R, flow, r0base, flbase, x, row_of(k), W, plane, in[k]);
-    ne_gather(R, r1base, in[0], x, row_of(0), W, H, plane, g[0]);
+#pragma unroll
+    for (int q = 0; q < GL; q++) ne_gather(R, r1base, in[q], x, row_of(q), W, H, plane, g[q]);
     for (int kb = 0; kb < NPH; kb += U) {
 #pragma unroll
         for (int kk = 0; kk < U; kk++) {
@@ -651,12 +656,12 @@ __global__ __launch_bounds__(64 * (NPROD + 2), (NPROD <= 4 ? 4 : 1)) void k_uvp(
                 // rows past the last entry (e >= NE, only in the final phase) are evaluated on clamped
                 // addresses and never consumed: no branch around the loads
                 float a[5];
-                ne_finish(in[kk & 3], g[kk & 1], x, row_of(k), W, H, a);
+                ne_finish(in[kk & 3], g[kk % GR], x, row_of(k), W, H, a);
                 const int slot = (NPROD * k + pi) % RSL;
 #pragma unroll
                 for (int c = 0; c < 5; c++) ringM[slot][c][lane] = a[c];
-                // refill: gathers of this wave's next entry, inputs three entries ahead
-                ne_gather(R, r1base, in[(kk + 1) & 3], x, row_of(k + 1), W, H, plane, g[(kk + 1) & 1]);
+                // refill: gathers of this wave's entry GL phases on, inputs three phases ahead
+                ne_gather(R, r1base, in[(kk + GL) & 3], x, row_of(k + GL), W, H, plane, g[(kk + GL) % GR]);
                 ne_load(R, flow, r0base, flbase, x, row_of(k + 3), W, plane, in[(kk + 3) & 3]);
             }
             __syncthreads();

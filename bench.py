@@ -54,7 +54,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 FP32_VALU_PEAK_TF = 157.3
-PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json"))
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "r04_pmc.json"), os.path.join(ROOT, "profiles", "r03_pmc.json"))
                  if os.path.exists(f)), os.path.join(ROOT, "profiles", "r03_pmc.json"))      # rocprofv3 --pmc passes of the fast mode
 PMC_FILE_EXACT = os.path.join(ROOT, "profiles", "r02_pmc.json")
 FP64_VALU_PEAK_TF = 78.6
