@@ -252,7 +252,7 @@ int avd_ws_reserve_fb(avd_ctx* ctx, int n)
         if (int e = dev_alloc(ctx, ws.d_pairdiff, np * kPairDiffTilesHost)) return e;
         if (ws.d_rlist) { (void)hipFree(ws.d_rlist); ws.d_rlist = nullptr; ws.rlist_cap = 0; }
         if (ws.h_rlist) { (void)hipHostFree(ws.h_rlist); ws.h_rlist = nullptr; }
-        if (hipHostMalloc((void**)&ws.h_rlist, sizeof(int) * np * 4) != hipSuccess) { ws.h_rlist = nullptr; ctx->err = "hipHostMalloc (re-run list)"; return AVD_ERR_NOMEM; }
+        if (hipHostMalloc((void**)&ws.h_rlist, sizeof(int) * np) != hipSuccess) { ws.h_rlist = nullptr; ctx->err = "hipHostMalloc (re-run list)"; return AVD_ERR_NOMEM; }
         if (ws.d_vs) { (void)hipFree(ws.d_vs); ws.d_vs = nullptr; }
         if (ws.d_vs0) { (void)hipFree(ws.d_vs0); ws.d_vs0 = nullptr; }
         if (ws.d_flow_il) { (void)hipFree(ws.d_flow_il); ws.d_flow_il = nullptr; }
@@ -351,12 +351,7 @@ static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h
         const int np = std::min(chunk, n - 1 - p0);
         const bool last = p0 + np >= n - 1;
         const uint8_t* base = d_small + (size_t)p0 * AVD_NPIX;
-        // the tail chunk of an asynchronous call: its early flag words go to the host beside the 320-px level (launch_farneback); not while per-kernel
-        // events are being recorded (the re-run's region would sit on another stream)
-        ctx->early_arm = flagged_mode && into_records && last && !host_wants && !ctx->profiling;
-        ctx->early_pending = 0;
         rc = launch_farneback(ctx, ctx->stream, base, np + 1, 0, 0);
-        ctx->early_arm = 0;
         if (rc) break;
         rc = launch_flow_stats(ctx, ctx->stream, np + 1, 0, 0);
         if (rc) break;
@@ -439,9 +434,6 @@ static int impl_create(int device_id, avd_ctx** out)
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_early, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_early_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
@@ -471,7 +463,6 @@ static void impl_destroy(avd_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->counted_in_flight) { ctx->counted_in_flight = 0; g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
     comm_destroy(ctx);
     free_ws(ctx->ws);
@@ -479,9 +470,6 @@ static void impl_destroy(avd_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
-    if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
-    if (ctx->ev_early_done) (void)hipEventDestroy(ctx->ev_early_done);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kern_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kmark_ev) if (e) (void)hipEventDestroy(e);
@@ -767,34 +755,16 @@ static int impl_synchronize(avd_ctx* ctx)
         avd_ctx* c;
         ~Uncount() { if (c->counted_in_flight) { c->counted_in_flight = 0; g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); } }
     } uncount{ctx};
-    if (!ctx->tail.active) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->tail.active) {
-        // fast Farneback mode: the pairs the level kernels flagged go through the exact kernels now (the workspace still holds the chunk), then the chunk's
-        // statistics and records are assembled again and fetched.  Pairs flagged by the 40- / 80- / 160-px levels are known BEFORE the 320-px launches end
-        // (their flag words came over on the second stream): their exact levels are started there at once, beside the fast 320-px launches, which skip them.
+        // fast Farneback mode: the records of the call's last chunk carry the level kernels' flag words; the pairs they mark go through the
+        // exact kernels now (the workspace still holds the chunk), the chunk's records are assembled again and fetched
         ctx->tail.active = 0;
         Workspace& ws = ctx->ws;
-        const int p0 = ctx->tail.p0, np = ctx->tail.np, fa = ctx->tail.fa, cap = ws.fb_cap;
-        int *E = ws.h_rlist, *L = ws.h_rlist + cap, *F = ws.h_rlist + 2 * (size_t)cap;
-        const int* early = ws.h_rlist + 3 * (size_t)cap;
-        int mE = 0, mL = 0, mF = 0;
-        const bool have_early = ctx->early_pending != 0;
-        if (have_early) {
-            ctx->early_pending = 0;
-            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_early_done));
-            for (int i = 0; i < np; i++) if (early[i] != 0) E[mE++] = i;
-            if (mE) if (int e = launch_farneback_rerun(ctx, ctx->stream2, E, mE, 0, np, 1, 0)) return e;
-        }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < np; i++)
-            if (ws.h_rec[p0 + 1 + i].reserved != 0) {
-                F[mF++] = i;
-                if (!(have_early && early[i] != 0)) L[mL++] = i;
-            }
-        if (mE) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));            // its flows are final; the two-kernel scratch is free again
-        if (mL) if (int e = launch_farneback_rerun(ctx, ctx->stream, L, mL, 0, np, 1, 1)) return e;
-        if (mF) {
-            if (int e = launch_farneback_rerun(ctx, ctx->stream, F, mF, 0, np, 2, 2)) return e;
+        const int p0 = ctx->tail.p0, np = ctx->tail.np, fa = ctx->tail.fa;
+        const int m = rerun_flagged(ctx, &ws.h_rec[p0 + 1].reserved, (int)(sizeof(avd_frame_record) / sizeof(int)), np);
+        if (m < 0) return m;
+        if (m > 0) {
             launch_records(ctx, p0, np, fa, ctx->tail.clipstart);
             HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec + fa, ws.d_rec + fa, sizeof(avd_frame_record) * (size_t)(p0 + np + 1 - fa), hipMemcpyDeviceToHost, ctx->stream));
             if (ctx->profiling && ctx->kmark_used > 0) kmark(ctx, AVD_K_COUNT);     // close the re-run's region

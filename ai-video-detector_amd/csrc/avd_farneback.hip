@@ -1357,15 +1357,6 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
             }
             if (k == 0 && g.prof && g.prof->kern_ev_used < 12) (void)hipEventRecord(g.prof->kern_ev[g.prof->kern_ev_used++], stream);
             ctx->ws.flow_res[k] = a;                       // the buffer written last
-            if (k == 1 && ctx->early_arm && fl && ctx->stream2) {
-                // the flag words as they stand after the 40- / 80- / 160-px levels travel to the host on the SECOND stream while the 320-px launches run: a call
-                // that is being drained by then starts the exact re-run of the pairs flagged so far beside them (impl_synchronize) instead of after them
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_early, stream));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_early, 0));
-                HIP_TRY(ctx, hipMemcpyAsync(ctx->ws.h_rlist + (size_t)3 * ctx->ws.fb_cap, fl, sizeof(int) * np, hipMemcpyDeviceToHost, ctx->stream2));
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_early_done, ctx->stream2));
-                ctx->early_pending = 1;
-            }
             // (pairs the level kernels flagged as ill-posed are re-run by the exact kernels once the HOST has seen the flags: launch_farneback_rerun)
             continue;
         }
@@ -1384,51 +1375,43 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
 // 64-row bands: ~0.15 ms per level for one pair, where the fused kernel's single workgroup per pair takes 0.23 / 0.83 ms however few pairs there are),
 // beyond that the fused kernels (one workgroup per pair = the exact mode's own launches, its time for a clip of nothing but flagged pairs).
 // ctx->fb_rerun_fused (tuning / tests): level mask of the fused kernel for the few-pairs case, default 0xC (40 and 80 px).
-int launch_farneback_rerun(avd_ctx* ctx, hipStream_t stream, const int* h_list, int m, int pair_off, int np_chunk, int part, int slot)
+int launch_farneback_rerun(avd_ctx* ctx, hipStream_t stream, const int* h_list, int m, int pair_off, int np_chunk)
 {
-    // part: bit 0 = the four levels (flow of the listed pairs), bit 1 = what follows them (|flow| and the two statistics of the listed pairs).  slot 0 .. 2:
-    // which third of the device list buffer the (pinned) host list is copied to -- a list on the second stream, a late list and the list of all flagged
-    // pairs can be alive at the same time (avd_capi.hip, impl_synchronize)
     if (m <= 0) return 0;
     Workspace& ws = ctx->ws;
-    if (m > ws.fb_cap || slot < 0 || slot > 2) { ctx->err = "re-run list longer than the chunk"; return AVD_ERR_ARG; }
+    if (m > ws.fb_cap) { ctx->err = "re-run list longer than the chunk"; return AVD_ERR_ARG; }
     if (!ws.d_rlist) {
-        if (int e = dev_alloc(ctx, ws.d_rlist, (size_t)3 * ws.fb_cap)) return e;
+        if (int e = dev_alloc(ctx, ws.d_rlist, (size_t)ws.fb_cap)) return e;
         ws.rlist_cap = ws.fb_cap;
     }
     const bool few = m <= kRerunTwoKernelMax;
     const int fused_mask = few ? (ctx->fb_rerun_fused & 0xF) : 0xF;
-    if ((part & 1) && fused_mask != 0xF && !ws.d_vs_rerun) {
+    if (fused_mask != 0xF && !ws.d_vs_rerun) {
         if (int e = dev_alloc(ctx, ws.d_vs0_rerun, (size_t)kRerunTwoKernelMax * 5 * S * 8)) return e;
         if (int e = dev_alloc(ctx, ws.d_vs_rerun, (size_t)kRerunTwoKernelMax * (5 * AVD_NPIX + 512))) return e;
     }
-    int* d_list = ws.d_rlist + (size_t)slot * ws.rlist_cap;
-    HIP_TRY(ctx, hipMemcpyAsync(d_list, h_list, sizeof(int) * m, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_rlist, h_list, sizeof(int) * m, hipMemcpyHostToDevice, stream));
     Seg g = make_seg(ctx, stream, 0, pair_off);
     g.prof = nullptr;
     g.vs = ws.d_vs_rerun; g.vs0 = ws.d_vs0_rerun;         // indexed by position in the list
-    const int* plist = d_list;
-    if (part & 1) {
-        if (stream == ctx->stream) kmark(ctx, AVD_K_RERUN);
-        for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
-            // levels 3 .. 1 work in the level's first flow buffer, level 0 in the buffer the fast kernels left their final flow in (the one the
-            // caller may read back)
-            float* flow = k == 0 ? const_cast<float*>(ws.flow_res[0]) : g.flow[k];
-            if (k == AVD_FB_LEVELS - 1) {
-                if (!((fused_mask >> k) & 1)) { ctx->err = "exact re-run: the coarsest level runs the fused kernel (it needs no cleared flow)"; return AVD_ERR_ARG; }
-            } else {
-                flow_up_level(stream, k, g.flow[k + 1], flow, m, plist);
-            }
-            if (int e = exact_level(ctx, g, k, m, flow, fused_mask, plist)) return e;
+    const int* plist = ws.d_rlist;
+    kmark(ctx, AVD_K_RERUN);
+    for (int k = AVD_FB_LEVELS - 1; k >= 0; k--) {
+        // levels 3 .. 1 work in the level's first flow buffer, level 0 in the buffer the fast kernels left their final flow in (the one the
+        // caller may read back)
+        float* flow = k == 0 ? const_cast<float*>(ws.flow_res[0]) : g.flow[k];
+        if (k == AVD_FB_LEVELS - 1) {
+            if (!((fused_mask >> k) & 1)) { ctx->err = "exact re-run: the coarsest level runs the fused kernel (it needs no cleared flow)"; return AVD_ERR_ARG; }
+        } else {
+            flow_up_level(stream, k, g.flow[k + 1], flow, m, plist);
         }
+        if (int e = exact_level(ctx, g, k, m, flow, fused_mask, plist)) return e;
     }
-    if (part & 2) {
-        float* mg = ws.d_mag + (size_t)pair_off * AVD_NPIX;
-        launch1d(k_mag, (int64_t)m * (AVD_NPIX / 4), 256, stream, (const float*)ws.flow_res[0], mg, (int64_t)m * (AVD_NPIX / 4), plist);
-        hipLaunchKernelGGL(k_stats_pair, dim3(m), dim3(512), 0, stream, (const float*)mg, g.stats, plist);
-        if (g.flow_il)                                        // the caller wants the dense flow (tests / debugging): interleave the chunk again
-            launch1d(k_flow_interleave, (int64_t)np_chunk * AVD_NPIX, 256, stream, (const float*)ws.flow_res[0], g.flow_il, (int64_t)np_chunk * AVD_NPIX);
-    }
+    float* mg = ws.d_mag + (size_t)pair_off * AVD_NPIX;
+    launch1d(k_mag, (int64_t)m * (AVD_NPIX / 4), 256, stream, (const float*)ws.flow_res[0], mg, (int64_t)m * (AVD_NPIX / 4), plist);
+    hipLaunchKernelGGL(k_stats_pair, dim3(m), dim3(512), 0, stream, (const float*)mg, g.stats, plist);
+    if (g.flow_il)                                        // the caller wants the dense flow (tests / debugging): interleave the chunk again
+        launch1d(k_flow_interleave, (int64_t)np_chunk * AVD_NPIX, 256, stream, (const float*)ws.flow_res[0], g.flow_il, (int64_t)np_chunk * AVD_NPIX);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

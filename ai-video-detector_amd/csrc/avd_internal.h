@@ -128,8 +128,8 @@ struct Workspace {
     int mag_valid = 0;                    // d_mag holds the magnitudes of the chunk being processed
     int* d_fbflags = nullptr;             // [n-1] ill-posedness flags of the fast level kernels (bit k: level k met the solver's criterion, bit 4 + k: the border-sign criterion); such pairs are re-run exactly
     int* d_pairdiff = nullptr;            // [n-1][20] "frame p differs from frame p + 1" per tile of the pyramid kernel's 160-px scale (all zero: bit-identical frames)
-    int* d_rlist = nullptr; int rlist_cap = 0;                  // exact re-run: the flagged pairs of a chunk, compacted by the host (three lists of rlist_cap entries)
-    int* h_rlist = nullptr;                                     // pinned: three lists of fb_cap entries (early / late / all flagged pairs) + the early flag words
+    int* d_rlist = nullptr; int rlist_cap = 0;                  // exact re-run: the flagged pairs of a chunk, compacted by the host
+    int* h_rlist = nullptr;                                     // pinned staging of that list
     double* d_vs_rerun = nullptr; double* d_vs0_rerun = nullptr; // the two-kernel path's double intermediate for kRerunTwoKernelMax pairs (allocated by the first re-run)
     double* d_vs = nullptr;               // [n-1] x 64x16 tiles of D = vsum(x+7)-vsum(x-8), double
     double* d_vs0 = nullptr;              // [n-1][5][320][8]  vsum columns 0..6 (row init)
@@ -156,9 +156,6 @@ struct avd_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;             // the exact re-run of pairs flagged EARLY (before the 320-px level) runs here, beside the 320-px launches
-    hipEvent_t ev_early = nullptr, ev_early_done = nullptr;
-    int early_arm = 0, early_pending = 0;      // the chunk being enqueued is the tail of an asynchronous call; its early flag words are on their way to the host
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_in = nullptr;                // avd_wait_stream: recorded on the caller's stream, waited for by ours
     avd_frame_record* pending_out = nullptr;   // caller buffer the pinned records are handed to in avd_synchronize
@@ -282,7 +279,7 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
 // avd_farneback.hip: exact re-run of the m flagged pairs h_list[0 .. m) (pair indices inside the chunk the workspace holds; h_list pinned) -- all four
 // levels with the exact kernels' launches from a compacted list, |flow| and the statistics of those pairs; np_chunk = pairs of the chunk
 constexpr int kRerunTwoKernelMax = 32;
-int launch_farneback_rerun(avd_ctx* ctx, hipStream_t stream, const int* h_list, int m, int pair_off, int np_chunk, int part = 3, int slot = 0);
+int launch_farneback_rerun(avd_ctx* ctx, hipStream_t stream, const int* h_list, int m, int pair_off, int np_chunk);
 // avd_norm.hip (extensions): LayerNorm over rows of 256..2048 values, softmax over rows of logits; device pointers
 int launch_layernorm(avd_ctx* ctx, const void* d_x, void* d_y, int bf16, long long rows, int cols, const float* d_gamma, const float* d_beta, float eps);
 int launch_softmax(avd_ctx* ctx, const float* d_x, float* d_y, long long rows, int cols);
