@@ -123,9 +123,11 @@ __device__ __forceinline__ void fb_barrier() { __syncthreads(); }
 // border_ind; profiles/r05_experiments.md section 1): it closes the checkerboard residual of round 4 (exactly periodic or static content, where
 // the true flow is zero and everything is residue) and fires on no natural / noisy / letterboxed pair of the 3 120-pair experiment.
 // chk (wave-uniform): flags are kept and the pair's two frames are not bit-identical (an exact duplicate's zero flow is structural in cv2 too).
+// skip (may be null): an LDS word that says, after the workgroup's FIRST barrier, that the pair is flagged already (k_fb_fast) -- every role then returns true
 template <typename Ge, bool UP, bool ZF = false>
-__device__ __forceinline__ void role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
-                                        const float* __restrict__ fring, int p, int x, int k, int lane, int* __restrict__ flags, bool chk)
+__device__ __forceinline__ bool role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
+                                        const float* __restrict__ fring, int p, int x, int k, int lane, int* __restrict__ flags, bool chk,
+                                        const volatile int* skip)
 {
     constexpr bool zf = ZF;
     constexpr int W = Ge::W, GD = Ge::GD, EPS = Ge::EPS;
@@ -150,7 +152,12 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
         if (UP) ne_load_r0(R, r0base, x, row, W, s);
         else ne_load(R, flow, r0base, flbase, x, row, W, plane, s);
     };
-    if (UP) fb_barrier();                                  // the chain wave has filled rows 0 .. 11 of the flow ring
+    bool first = skip != nullptr;                          // the first barrier of this role has not been passed yet
+    if (UP) {
+        fb_barrier();                                      // the chain wave has filled rows 0 .. 11 of the flow ring
+        if (first && *skip) return true;
+        first = false;
+    }
 #pragma unroll
     for (int i = 0; i < NIS - 1; i++) load_in(row_of(ent(i)), in[i]);
     if (UP) {
@@ -205,6 +212,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
 #pragma unroll
         for (int q = 0; q < U; q++) {
             fb_barrier();
+            if (first) { first = false; if (*skip) return true; }
             work(t0 + q, q);
         }
     }
@@ -216,6 +224,7 @@ __device__ __forceinline__ void role_ne(const float* __restrict__ R, const float
     for (int t = TN; t < Ge::T; t++) fb_barrier();
     if (chk && __builtin_amdgcn_ballot_w64(ill) != 0 && lane == 0) atomicOr(flags + p, 16 << (Ge::W == 320 ? 0 : Ge::W == 160 ? 1 : Ge::W == 80 ? 2 : 3));
     FBF_WAIT_OUT(threadIdx.x >> 6, k, fbf_t0)
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -272,8 +281,8 @@ __device__ __forceinline__ void up_finish(float* __restrict__ fring, int g, int 
 }
 
 template <typename Ge, bool UP>
-__device__ __forceinline__ void role_chain(const float* __restrict__ mring, double* __restrict__ vsring, float* __restrict__ fring,
-                                           const float* __restrict__ prev, int p, int b, int x, int lane)
+__device__ __forceinline__ bool role_chain(const float* __restrict__ mring, double* __restrict__ vsring, float* __restrict__ fring,
+                                           const float* __restrict__ prev, int p, int b, int x, int lane, const volatile int* skip)
 {
     constexpr int W = Ge::W;
     FBF_WAIT_DECL
@@ -287,16 +296,20 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
     double* vdst = vsring + 8 + 64 * b + lane;
     const unsigned pbase = (unsigned)p * 2u * (W / 2) * (H / 2);
     UpRows<Ge> up;
+    bool first = skip != nullptr;
     if (UP) {
 #pragma unroll
         for (int g = 0; g < 3; g++) { up_issue<Ge>(prev, pbase, g, x, up); up_finish<Ge>(fring, g, x, lane, up); }
         fb_barrier();
+        if (first && *skip) return true;
+        first = false;
     }
     for (int t4 = 0; t4 < Ge::T; t4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int t = t4 + q;
             fb_barrier();
+            if (first) { first = false; if (*skip) return true; }
             const bool up_now = UP && 4 * (t + 3) < H;                       // wave-uniform
             if (up_now) up_issue<Ge>(prev, pbase, t + 3, x, up);             // consumed after the chain work of this step
             if (t >= 1) {
@@ -342,6 +355,7 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
         }
     }
     FBF_WAIT_OUT(threadIdx.x >> 6, 2, fbf_t0)
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -361,8 +375,8 @@ __device__ __forceinline__ void role_chain(const float* __restrict__ mring, doub
 //                                                            level (the same experiment: <= 0.25 W on well-posed pairs)
 // written so that a NaN or a negative determinant also fires.
 template <typename Ge, bool UP>
-__device__ __forceinline__ void role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, float* __restrict__ mag_out,
-                                           int* __restrict__ flags, int p, int b, int xi, int lane, int o0, int ow)
+__device__ __forceinline__ bool role_solve(const double* __restrict__ vsring, float* __restrict__ flow_out, float* __restrict__ mag_out,
+                                           int* __restrict__ flags, int p, int b, int xi, int lane, int o0, int ow, const volatile int* skip)
 {
     FBF_WAIT_DECL
 #ifdef AVD_FBF_DEBUG
@@ -374,13 +388,19 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
     const bool colok = CPL * j < ow;
     float* fl = flow_out + (size_t)p * 2 * plane + o0 + CPL * j;
     const double* vsrc = vsring + 8 + CPL * j;
-    if (UP) fb_barrier();                                  // the chain wave's fill of the flow ring
+    bool first = skip != nullptr;
+    if (UP) {
+        fb_barrier();                                      // the chain wave's fill of the flow ring
+        if (first && *skip) return true;
+        first = false;
+    }
     bool ill = false;
     for (int t4 = 0; t4 < Ge::T; t4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int t = t4 + q;
             fb_barrier();
+            if (first) { first = false; if (*skip) return true; }
             const int y = 4 * t - 15 + r;
 #ifdef AVD_FBF_NOSOLVE
             if (false) {
@@ -448,6 +468,7 @@ __device__ __forceinline__ void role_solve(const double* __restrict__ vsring, fl
     }
     if (flags && __builtin_amdgcn_ballot_w64(ill) != 0 && lane == 0) atomicOr(flags + p, 1 << (Ge::W == 320 ? 0 : Ge::W == 160 ? 1 : Ge::W == 80 ? 2 : 3));
     FBF_WAIT_OUT(threadIdx.x >> 6, 3, fbf_t0)
+    return false;
 }
 
 // between two phases of a launch that hand the flow over through global memory (prologue -> first iteration, iteration -> next
@@ -488,9 +509,6 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     const int p = (blockIdx.x & 7) * ppx + local / nstrips;
     const int s = local % nstrips;
     if (p >= npairs) return;                              // whole workgroup
-    // a pair that an earlier launch (or another strip, a moment ago) has flagged is re-run by the exact kernels whatever happens here: skip it
-    // (a clip of nothing but such pairs then costs the exact mode's time, not the sum of both)
-    if (flags && __builtin_nontemporal_load(flags + p) != 0) return;
     const int o0 = s * ow;
     const int width = o0 + ow <= W ? ow : W - o0;         // output columns of this strip (multiples of 4)
     // Waves w, w + 4, w + 8 of a workgroup share a SIMD.  Issue cycles per step: X ~ 900 (double), N ~ 550, C ~ 230: with
@@ -509,6 +527,10 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     const int x = xu < 0 ? 0 : (xu > W - 1 ? W - 1 : xu);
     float* mring = mrings + b * 8 * Ge::M_SLOT;
     float* fring = reinterpret_cast<float*>(lds + Ge::LDS_DOUBLES) + b * 16 * Ge::F_SLOT;   // UP only
+    // ONE lane reads the pair's flag word (every thread reading it for itself could see different values while another strip of the pair raises it:
+    // waves of one workgroup would part ways at a barrier)
+    __shared__ int s_skip;
+    if (flags && role == Ge::NPB + 1 && b == 0 && lane == 0) s_skip = __builtin_nontemporal_load(flags + p);
     if (PRO) {
         // columns any lane of this strip reads: [o0 - 7, o0 - 7 + 64 NB) clamped to the image, widened to whole chunks of four
         constexpr int H = W, plane = W * H, pplane = (W / 2) * (H / 2);
@@ -521,7 +543,13 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
             *reinterpret_cast<float4*>(flow_tmp + ((size_t)p * 2 + c) * plane + dy * W + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
         phase_sync();
+        if (flags && s_skip) return;                       // (behind the prologue's own barrier: workgroup-uniform)
     }
+    // A pair that an earlier launch (or another strip, a moment ago) has flagged is re-run by the exact kernels whatever happens here: the workgroup
+    // leaves (a clip of nothing but such pairs then costs the exact mode's time, not the sum of both).  The flag word is read by ONE lane of a solver wave
+    // -- which has nothing to do during the first two steps -- into LDS, and every role looks at it after the workgroup's first barrier: the read's
+    // latency hides behind the normal-equation waves' first loads instead of standing in front of them (at the head of the kernel it cost 1.5-2.5 % of the launch)
+    const volatile int* skip = (flags && !PRO) ? &s_skip : nullptr;
     const float* fin0 = PRO ? flow_tmp : flow_in;
     if (role < Ge::NPB) {
         // border-sign criterion: not for a pair of bit-identical frames (the pyramid kernel left "frame p differs from frame p + 1" per tile)
@@ -531,21 +559,23 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
         for (int it = 0; it < IT; it++) {
             if (it > 0) phase_sync();
             const float* fin = it == 0 ? fin0 : ((it & 1) ? flow_out : flow_tmp);
-            if (Ge::W == 40 && zero_first != 0 && it == 0) role_ne<Ge, UP, Ge::W == 40>(R, fin, mring, fring, p, x, role, lane, flags, chk);
-            else role_ne<Ge, UP, false>(R, fin, mring, fring, p, x, role, lane, flags, chk);
+            const volatile int* sk = it == 0 ? skip : nullptr;
+            if (Ge::W == 40 && zero_first != 0 && it == 0) { if (role_ne<Ge, UP, Ge::W == 40>(R, fin, mring, fring, p, x, role, lane, flags, chk, sk)) return; }
+            else if (role_ne<Ge, UP, false>(R, fin, mring, fring, p, x, role, lane, flags, chk, sk)) return;
         }
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
 #pragma unroll 1
         for (int it = 0; it < IT; it++) {
             if (it > 0) phase_sync();
-            role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane);
+            if (role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane, it == 0 ? skip : nullptr)) return;
         }
     } else {
 #pragma unroll 1
         for (int it = 0; it < IT; it++) {
             if (it > 0) phase_sync();
-            role_solve<Ge, UP>(vsring, (it & 1) ? flow_tmp : flow_out, it == IT - 1 ? mag_out : nullptr, flags, p, b, role - Ge::NPB - 1, lane, o0, width);
+            if (role_solve<Ge, UP>(vsring, (it & 1) ? flow_tmp : flow_out, it == IT - 1 ? mag_out : nullptr, flags, p, b, role - Ge::NPB - 1, lane, o0, width,
+                                   it == 0 ? skip : nullptr)) return;
         }
     }
 }
