@@ -940,6 +940,7 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun_fused") == 0) { *value = ctx->fb_rerun_fused; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { *value = ctx->fb_wide160; return AVD_OK; }
+    if (std::strcmp(name, "fb_wide160_used") == 0) { *value = ctx->fb_wide160_used; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { *value = ctx->fb_fold_blur; return AVD_OK; }
     if (std::strcmp(name, "gemm_waves") == 0) { *value = ctx->gemm_waves; return AVD_OK; }
     if (std::strcmp(name, "cnn_tiles") == 0) { *value = ctx->cnn_tiles; return AVD_OK; }

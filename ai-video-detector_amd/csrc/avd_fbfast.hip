@@ -638,7 +638,8 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
         // columns, 14 halo columns per pair instead of 28) and that is what counts with clips in flight: +2.4 % frames/s.  The two differ in the
         // grouping of the solver's window sums (four columns per lane against two): bit-identical on well-posed content, like the 320-px level.
         // 2 = choose per call: this call is being enqueued and not yet counted, so > 0 means SOMEBODY ELSE's kernels will share the chip with it
-        if (ctx->fb_wide160 == 1 || (ctx->fb_wide160 == 2 && avd_calls_in_flight() - ctx->counted_in_flight > 0)) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 160, zero_first, mode);
+        ctx->fb_wide160_used = ctx->fb_wide160 == 1 || (ctx->fb_wide160 == 2 && avd_calls_in_flight() - ctx->counted_in_flight > 0);
+        if (ctx->fb_wide160_used) launch_fast<FGeo<160, 3, 2, 2, 1>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 160, zero_first, mode);
         else launch_fast<FGeo<160, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 2, 80, zero_first, mode);
         break;
     case 80: launch_fast<FGeo<80, 2, 1, 4, 2>>(stream, R, flow_in, flow_out, flow_tmp, nullptr, flags, pairdiff, np, 1, 80, zero_first, mode); break;

@@ -188,6 +188,7 @@ struct avd_ctx {
     int fb_wide160 = 2;             // fast mode: the 160-px level as one three-block strip per pair (1: fewer CU-microseconds, throughput) or as two strips (0: shorter launches, latency);
                                     // 2 (default) = by what is in flight when the call is enqueued: one strip if another context of the process holds an undrained call, two if this clip is alone; AVD_FB_WIDE160 / avd_set_option
     int counted_in_flight = 0;      // this context's enqueued call is counted in avd_calls_in_flight()
+    int fb_wide160_used = 0;        // the shape the last call's 160-px launches took (read-only option "fb_wide160_used")
     int gemm_waves = 8;             // patch-embed GEMM: waves per workgroup (8: 8 x 4 MFMA tiles per wave, 16: 4 x 4; measured no faster), the same 256 x 256 tile; AVD_GEMM_WAVES / avd_set_option
     int cnn_chunk = 128;            // CNN extension: frames per forward pass (activation scratch = 4 x 1.6 MB per frame)
     int cnn_fuse = 2;               // CNN extension: a block's 3x3 and expanding 1x1 in one launch (stages 1, 2): 2 = with the 3x3's input slab in LDS in the stride-1 blocks (k_slab3_expand), 1 = gathering kernels only, 0 = layer by layer

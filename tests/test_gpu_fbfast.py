@@ -331,3 +331,22 @@ def test_modes_can_be_switched_on_one_context(oracle):
                     assert np.array_equal(flow[p], want[p]), (mode, hex(fused), p)
                 else:
                     assert np.abs(flow[p] - want[p]).max() <= FLOW_TOL, (mode, hex(fused), p)
+
+
+def test_the_160_px_shape_follows_what_is_in_flight(oracle):
+    """fb_wide160 = 2 (default): a call enqueued while another context of the process holds an undrained call runs the 160-px level as one strip per pair
+    (fewer CU-microseconds), a call that has the chip to itself as two strips (shorter launches); the records are the same either way."""
+    import avd_hip
+    clip = synth.make_clip(6, 360, 640, seed=31, dup_every=0)
+    with avd_hip.Context(0) as a, avd_hip.Context(0) as b:
+        alone = b.analyze_frames(clip)
+        assert b.get_option("fb_wide160_used") == 0
+        rec = np.zeros(len(clip), avd_hip.RECORD_DTYPE)
+        keep = a.analyze_frames_async(clip, rec)               # enqueued, not drained
+        shared = b.analyze_frames(clip)
+        assert b.get_option("fb_wide160_used") == 1
+        a.synchronize()
+        del keep
+        assert np.array_equal(alone, shared) and np.array_equal(rec, alone)
+        again = b.analyze_frames(clip)
+        assert b.get_option("fb_wide160_used") == 0 and np.array_equal(again, alone)
