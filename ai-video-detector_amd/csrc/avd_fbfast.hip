@@ -330,7 +330,7 @@ __device__ __forceinline__ bool role_chain(const float* __restrict__ mring, doub
             if (y >= H) break;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (((y - y0) * 4 + q) % 3 != b) continue;               // wave-uniform; of a step's 16 pieces block 0's chain wave takes 6, the others 5
+                if ((y * 4 + q) % 3 != b) continue;                      // wave-uniform
                 if (q < 3 || lane < (kWinRowBytes - 3 * 1024) / 16)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r1rows + (size_t)y * (W * 20) + q * 1024 + lane * 16),
                                                      (__attribute__((address_space(3))) void*)(wring + (y % kWinRows) * kWinRowBytes + q * 1024), 16, 0, 0);
@@ -354,12 +354,7 @@ __device__ __forceinline__ bool role_chain(const float* __restrict__ mring, doub
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int t = t4 + q;
-            if (WIN) {
-                // the rows the normal-equation waves may read from this barrier on were issued TWO steps ago: the last step's pieces (6 or 5 of them, as long as
-                // its four rows were all inside the image) may stay in flight -- two steps (~3 us) of latency tolerance for a row that comes from HBM
-                if (4 * t + 14 < H) { if (b == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the rows issued during the last step have landed: a step later than they are read at the earliest
             fb_barrier();
             if (first) { first = false; if (*skip) return true; }
             if (WIN) stage(4 * t + 13 + kWinDy, 4 * t + 17 + kWinDy);        // rows (yhi(t + 1), yhi(t + 2)]: into the slots of rows below ylo(t)
