@@ -448,7 +448,6 @@ static int impl_create(int device_id, avd_ctx** out)
         if (const char* e = std::getenv("AVD_FB_FOLD_BLUR")) ctx->fb_fold_blur = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_FB_MODE")) ctx->fb_mode = (std::strcmp(e, "exact") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
         if (const char* e = std::getenv("AVD_FB_RERUN")) ctx->fb_rerun = std::atoi(e) != 0;
-        if (const char* e = std::getenv("AVD_FB_WIN")) ctx->fb_win = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVD_GEMM_WAVES")) ctx->gemm_waves = std::atoi(e) == 16 ? 16 : 8;
         build_fb_consts(ctx->fbc);
         ok = hipMalloc(&ctx->d_fbc, sizeof(FbConsts)) == hipSuccess &&
@@ -915,7 +914,6 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_mode") == 0) { ctx->fb_mode = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 7; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
-    if (std::strcmp(name, "fb_win") == 0) { ctx->fb_win = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun_fused") == 0) { ctx->fb_rerun_fused = (value & 0xF) | 8; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value == 0 ? 0 : (value == 1 ? 1 : 2); return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { ctx->fb_fold_blur = value != 0; return AVD_OK; }
@@ -940,7 +938,6 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_mode") == 0) { *value = ctx->fb_mode; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_up") == 0) { *value = ctx->fb_fold_up; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
-    if (std::strcmp(name, "fb_win") == 0) { *value = ctx->fb_win; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun_fused") == 0) { *value = ctx->fb_rerun_fused; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { *value = ctx->fb_wide160; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160_used") == 0) { *value = ctx->fb_wide160_used; return AVD_OK; }

@@ -1350,7 +1350,7 @@ int launch_farneback(avd_ctx* ctx, hipStream_t stream, const uint8_t* d_small, i
                 for (int it = 0; it < 3; it++) {
                     float* mag = (k == 0 && it == 2) ? ctx->ws.d_mag + (size_t)pair_off * AVD_NPIX : nullptr;
                     const bool first_prev = prev_in && it == 0;
-                    const int mode = !first_prev ? ((k == 0 && ctx->fb_win) ? 5 : 0) : (fold_chain ? 1 : 2);
+                    const int mode = !first_prev ? 0 : (fold_chain ? 1 : 2);
                     if (int e = launch_fb_fast(ctx, stream, w, g.poly[k], first_prev ? prev : a, b, a, mag, fl, pd, np, k == AVD_FB_LEVELS - 1 && it == 0, mode)) return e;
                     float* t = a; a = b; b = t;
                 }

@@ -84,13 +84,6 @@ struct FGeo {
     static_assert(H % 4 == 0 && (NPB == 2 || NPB == 4) && (XPB == 1 || XPB == 2), "whole groups of image rows");
 };
 
-// WIN (round 5, the 320-px level's second and third launch): the bilinear gathers of R1 -- six vector-memory instructions per entry, 72 of the 129 a
-// workgroup issues per step, on the texture addresser that co-limits this kernel -- are served from an LDS WINDOW of R1 rows instead.  The three chain
-// waves (which issue no other vector-memory instruction) stream rows of R1 into a ring of kWinRows rows x 192 columns by LDS-DMA, two steps ahead of the
-// normal-equation waves; a wave whose 64 warped positions all fall inside the window (vertical flow in [-2, +3) px, horizontal >= 6 px of room) reads
-// its twenty floats per entry from LDS; a wave with any position outside gathers from memory as before (wave-uniform choice, same values either way).
-constexpr int kWinRows = 17, kWinCols = 192, kWinRowBytes = kWinCols * 20, kWinBytes = kWinRows * kWinRowBytes, kWinDy = 2;
-
 // workgroup barrier; debug builds (-DAVD_FBF_DEBUG) account the cycles a wave spends waiting at it
 #ifdef AVD_FBF_DEBUG
 __device__ long long g_fbf_stamps[16][3];               // [wave][total cycles, cycles at barriers, role] of workgroup 0
@@ -131,10 +124,10 @@ __device__ __forceinline__ void fb_barrier() { __syncthreads(); }
 // the true flow is zero and everything is residue) and fires on no natural / noisy / letterboxed pair of the 3 120-pair experiment.
 // chk (wave-uniform): flags are kept and the pair's two frames are not bit-identical (an exact duplicate's zero flow is structural in cv2 too).
 // skip (may be null): an LDS word that says, after the workgroup's FIRST barrier, that the pair is flagged already (k_fb_fast) -- every role then returns true
-template <typename Ge, bool UP, bool ZF = false, bool WIN = false>
+template <typename Ge, bool UP, bool ZF = false>
 __device__ __forceinline__ bool role_ne(const float* __restrict__ R, const float* __restrict__ flow, float* __restrict__ mring,
                                         const float* __restrict__ fring, int p, int x, int k, int lane, int* __restrict__ flags, bool chk,
-                                        const volatile int* skip, const char* __restrict__ wring = nullptr, int wx0 = 0)
+                                        const volatile int* skip)
 {
     constexpr bool zf = ZF;
     constexpr int W = Ge::W, GD = Ge::GD, EPS = Ge::EPS;
@@ -154,22 +147,6 @@ __device__ __forceinline__ bool role_ne(const float* __restrict__ R, const float
     const bool chkx = chk && __builtin_amdgcn_ballot_w64(xz) != 0;   // wave-uniform: only the first block of the first strip holds column 0
     bool ill = false;
     auto gather = [&](const NeIn& s, int row, NeG2& gs) __attribute__((always_inline)) { ne_gather2(R, r1base, s, x, row, W, H, gs, zf); };
-    // WIN: the same sample from the LDS window when all 64 positions are inside it at step t (rows [4 t + 2, 4 t + 10] are resident: role_chain)
-    auto gather_win = [&](const NeIn& s, int row, NeG2& gs, int t) __attribute__((always_inline)) {
-        const float fx = x + s.dx, fy = row + s.dy;
-        const float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
-        const int x1 = clampi((int)flx, 0, W - 2), y1 = clampi((int)fly, 0, H - 2);
-        const int yhi = 4 * t + 8 + kWinDy < H - 1 ? 4 * t + 8 + kWinDy : H - 1;
-        const bool inwin = x1 >= wx0 && x1 + 1 <= wx0 + kWinCols - 1 && y1 >= 4 * t + 4 - kWinDy && y1 + 1 <= yhi;
-        if (__builtin_amdgcn_ballot_w64(!inwin) != 0) { ne_gather2(R, r1base, s, x, row, W, H, gs, zf); return; }
-        gs.fx = fx - flx; gs.fy = fy - fly;
-        gs.inside = flx >= 0.f && flx <= (float)(W - 2) && fly >= 0.f && fly <= (float)(H - 2);
-        const unsigned xo = (unsigned)(x1 - wx0) * 20u;
-        const float* tp = reinterpret_cast<const float*>(wring + (unsigned)(y1 % kWinRows) * kWinRowBytes + xo);
-        const float* bp = reinterpret_cast<const float*>(wring + (unsigned)((y1 + 1) % kWinRows) * kWinRowBytes + xo);
-        gs.t0 = fv4{tp[0], tp[1], tp[2], tp[3]}; gs.t1 = fv4{tp[4], tp[5], tp[6], tp[7]}; gs.t2 = fv2{tp[8], tp[9]};
-        gs.b0 = fv4{bp[0], bp[1], bp[2], bp[3]}; gs.b1 = fv4{bp[4], bp[5], bp[6], bp[7]}; gs.b2 = fv2{bp[8], bp[9]};
-    };
     auto flow_of = [&](int row, NeIn& s) { const float* f = fring + (row & 15) * Ge::F_SLOT + lane; s.dx = f[0]; s.dy = f[64]; };
     auto load_in = [&](int row, NeIn& s) {
         if (UP) ne_load_r0(R, r0base, x, row, W, s);
@@ -197,8 +174,7 @@ __device__ __forceinline__ bool role_ne(const float* __restrict__ R, const float
             // refills first: the gather GD entries ahead goes into the slot the previous entry released, the inputs
             // NIS - 1 entries ahead into the slot of the entry before this one (rows beyond the image clamp to the last)
 #ifndef AVD_FBF_NOGATHER          // timing-only ablation builds (results are wrong)
-            if constexpr (WIN) gather_win(in[(ii + GD) % NIS], row_of(ent(i + GD)), g[(ii + GD) % NGS], t);
-            else gather(in[(ii + GD) % NIS], row_of(ent(i + GD)), g[(ii + GD) % NGS]);
+            gather(in[(ii + GD) % NIS], row_of(ent(i + GD)), g[(ii + GD) % NGS]);
 #endif
 #ifndef AVD_FBF_NOINLOAD
             load_in(row_of(ent(i + NIS - 1)), in[(ii + NIS - 1) % NIS]);
@@ -304,10 +280,9 @@ __device__ __forceinline__ void up_finish(float* __restrict__ fring, int g, int 
     }
 }
 
-template <typename Ge, bool UP, bool WIN = false>
+template <typename Ge, bool UP>
 __device__ __forceinline__ bool role_chain(const float* __restrict__ mring, double* __restrict__ vsring, float* __restrict__ fring,
-                                           const float* __restrict__ prev, int p, int b, int x, int lane, const volatile int* skip,
-                                           const float* __restrict__ R = nullptr, char* __restrict__ wring = nullptr, int wx0 = 0)
+                                           const float* __restrict__ prev, int p, int b, int x, int lane, const volatile int* skip)
 {
     constexpr int W = Ge::W;
     FBF_WAIT_DECL
@@ -322,27 +297,6 @@ __device__ __forceinline__ bool role_chain(const float* __restrict__ mring, doub
     const unsigned pbase = (unsigned)p * 2u * (W / 2) * (H / 2);
     UpRows<Ge> up;
     bool first = skip != nullptr;
-    // WIN: this wave's share (every third 1-KiB piece) of rows [y0, y1) of R1 into the window ring, by LDS-DMA; returns the number of instructions issued
-    const char* r1rows = WIN ? reinterpret_cast<const char*>(R) + ((size_t)(p + 1) * 5 * W * H + (size_t)wx0 * 5) * 4 : nullptr;
-    auto stage = [&](int y0, int y1) __attribute__((always_inline)) {
-        int n = 0;
-        for (int y = y0; y < y1; y++) {
-            if (y >= H) break;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if ((y * 4 + q) % 3 != b) continue;                      // wave-uniform
-                if (q < 3 || lane < (kWinRowBytes - 3 * 1024) / 16)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r1rows + (size_t)y * (W * 20) + q * 1024 + lane * 16),
-                                                     (__attribute__((address_space(3))) void*)(wring + (y % kWinRows) * kWinRowBytes + q * 1024), 16, 0, 0);
-                n++;
-            }
-        }
-        return n;
-    };
-    if (WIN) {
-        stage(0, 13 + kWinDy);                              // rows the first two steps' gathers may touch: [0, 15); step t then adds rows 4 t + 15 .. 4 t + 18
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     if (UP) {
 #pragma unroll
         for (int g = 0; g < 3; g++) { up_issue<Ge>(prev, pbase, g, x, up); up_finish<Ge>(fring, g, x, lane, up); }
@@ -354,10 +308,8 @@ __device__ __forceinline__ bool role_chain(const float* __restrict__ mring, doub
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int t = t4 + q;
-            if (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the rows issued during the last step have landed: a step later than they are read at the earliest
             fb_barrier();
             if (first) { first = false; if (*skip) return true; }
-            if (WIN) stage(4 * t + 13 + kWinDy, 4 * t + 17 + kWinDy);        // rows (yhi(t + 1), yhi(t + 2)]: into the slots of rows below ylo(t)
             const bool up_now = UP && 4 * (t + 3) < H;                       // wave-uniform
             if (up_now) up_issue<Ge>(prev, pbase, t + 3, x, up);             // consumed after the chain work of this step
             if (t >= 1) {
@@ -537,7 +489,7 @@ __device__ __forceinline__ void phase_sync()
 //     pole of a step and cannot take the resize on, while a prologue costs ~1 us and saves k_flow_up's launch.
 // IT  iterations inside the launch (levels whose pairs are ONE strip: no other workgroup reads this one's flow): the flow ping-pongs
 //     between flow_out and flow_tmp through L2, one workgroup barrier between iterations; the result is in flow_out (IT odd).
-template <typename Ge, bool UP, int IT = 1, bool PRO = false, bool WIN = false>
+template <typename Ge, bool UP, int IT = 1, bool PRO = false>
 __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __restrict__ R, const float* flow_in, float* flow_out, float* flow_tmp,
                                                               float* __restrict__ mag_out, int* __restrict__ flags, const int* __restrict__ pairdiff,
                                                               int npairs, int nstrips, int ow, int zero_first, int dbg)
@@ -545,10 +497,7 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     constexpr int W = Ge::W, NB = Ge::NB;
     static_assert(IT == 1 || IT == 3, "one iteration per launch, or all three");
     static_assert(!(UP && (PRO || IT > 1)), "the chain wave's resize is the 320-px launch's");
-    static_assert(!WIN || (!UP && !PRO && IT == 1 && W == 320 && NB == 3 && Ge::GD == 2 && Ge::EPS == 2), "the R1 window is the 320-px launch's (no room beside the flow ring of the first one)");
-    static_assert(!WIN || Ge::LDS_DOUBLES * 8 + kWinBytes + 64 <= 163840, "LDS: rings + window");
-    __shared__ __align__(16) double lds[Ge::LDS_DOUBLES + (UP ? Ge::F_FLOATS / 2 : 0) + (WIN ? kWinBytes / 8 : 0)];
-    char* wring = reinterpret_cast<char*>(lds + Ge::LDS_DOUBLES);                      // WIN only
+    __shared__ __align__(16) double lds[Ge::LDS_DOUBLES + (UP ? Ge::F_FLOATS / 2 : 0)];
     double* vsring = lds;
     float* mrings = reinterpret_cast<float*>(lds + Ge::VS_DOUBLES);
     const int lane = threadIdx.x & 63;
@@ -562,7 +511,6 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     if (p >= npairs) return;                              // whole workgroup
     const int o0 = s * ow;
     const int width = o0 + ow <= W ? ow : W - o0;         // output columns of this strip (multiples of 4)
-    const int wx0 = s == 0 ? 0 : W - kWinCols;            // WIN: first image column of this strip's R1 window
     // Waves w, w + 4, w + 8 of a workgroup share a SIMD.  Issue cycles per step: X ~ 900 (double), N ~ 550, C ~ 230: with
     // NB = 3 the SIMDs get {X, N1, C} of block 0, 1, 2 and {N0, N0, N0} -- 1700 / 1700 / 1700 / 1650 cycles
     // role: 0 .. NPB-1 normal equations, NPB the chain, NPB+1 .. solvers
@@ -613,14 +561,14 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
             const float* fin = it == 0 ? fin0 : ((it & 1) ? flow_out : flow_tmp);
             const volatile int* sk = it == 0 ? skip : nullptr;
             if (Ge::W == 40 && zero_first != 0 && it == 0) { if (role_ne<Ge, UP, Ge::W == 40>(R, fin, mring, fring, p, x, role, lane, flags, chk, sk)) return; }
-            else if (role_ne<Ge, UP, false, WIN>(R, fin, mring, fring, p, x, role, lane, flags, chk, sk, wring, wx0)) return;
+            else if (role_ne<Ge, UP, false>(R, fin, mring, fring, p, x, role, lane, flags, chk, sk)) return;
         }
     } else if (role == Ge::NPB) {
         if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);    // the only sequential part: take the issue slot whenever ready
 #pragma unroll 1
         for (int it = 0; it < IT; it++) {
             if (it > 0) phase_sync();
-            if (role_chain<Ge, UP, WIN>(mring, vsring, fring, flow_in, p, b, x, lane, it == 0 ? skip : nullptr, R, wring, wx0)) return;
+            if (role_chain<Ge, UP>(mring, vsring, fring, flow_in, p, b, x, lane, it == 0 ? skip : nullptr)) return;
         }
     } else {
 #pragma unroll 1
@@ -632,7 +580,7 @@ __global__ __launch_bounds__((64 * Ge::NWAVES)) void k_fb_fast(const float* __re
     }
 }
 
-// mode: 0 = one iteration flow_in -> flow_out; 5 (320 px) = the same with the R1 window in LDS (WIN); 1 (320 px) = the same with the chain wave's resize of the previous level's flow; 2 = one
+// mode: 0 = one iteration flow_in -> flow_out; 1 (320 px) = the same with the chain wave's resize of the previous level's flow; 2 = one
 // iteration behind a prologue that resizes the previous level's flow into flow_tmp; 3 = all three iterations (flow_in ignored when
 // zero_first, result in flow_out); 4 = prologue + all three iterations
 template <typename Ge>
@@ -656,9 +604,6 @@ void launch_fast(hipStream_t stream, const float* R, const float* fin, float* fo
     if constexpr (Ge::W == 80 || Ge::W == 40) {
         if (mode == 3) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 3, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, zero_first, dbg); return; }
     }
-    if constexpr (Ge::W == 320) {
-        if (mode == 5) { hipLaunchKernelGGL((k_fb_fast<Ge, false, 1, false, true>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, 0, dbg); return; }
-    }
     hipLaunchKernelGGL((k_fb_fast<Ge, false>), g, t, 0, stream, R, fin, fout, ftmp, mag, flags, pairdiff, np, nstrips, ow, zero_first, dbg);
 }
 
@@ -677,7 +622,7 @@ int launch_fb_fast(avd_ctx* ctx, hipStream_t stream, int w, const float* R, cons
                    int* flags, const int* pairdiff, int np, int zero_first, int mode)
 {
     if (np <= 0) return 0;
-    const bool ok = mode == 0 || ((mode == 1 || mode == 5) && w == 320) || (mode == 2 && (w == 160 || w == 80)) || (mode == 3 && (w == 80 || w == 40)) || (mode == 4 && w == 80);
+    const bool ok = mode == 0 || (mode == 1 && w == 320) || (mode == 2 && (w == 160 || w == 80)) || (mode == 3 && (w == 80 || w == 40)) || (mode == 4 && w == 80);
     if (!ok) { ctx->err = "launch_fb_fast: this mode does not exist at this level size"; return AVD_ERR_ARG; }
     if (flow_in == flow_out || (mode >= 2 && (!flow_tmp || flow_tmp == flow_out))) { ctx->err = "launch_fb_fast: the flow is not updated in place"; return AVD_ERR_ARG; }
     switch (w) {

@@ -198,7 +198,6 @@ struct avd_ctx {
                                     // iterations in one launch
     int fb_mode = 1;                // 1 = fast level kernel (avd_fbfast.hip: literal vertical chain, direct horizontal window sums; flow within
                                     // 1e-5 px of the oracle, in practice identical), 0 = exact (avd_fbfused.hip / two-kernel path: bit-identical)
-    int fb_win = 1;                 // fast mode: the 320-px level's second and third launch read the bilinear samples of R1 from an LDS window (avd_fbfast.hip, WIN); 0 = gathers from memory (A/B; no effect on results); AVD_FB_WIN / avd_set_option
     int fb_rerun = 1;               // fast mode: pairs the level kernels flag as ill-posed are re-run by the exact kernels (launch_farneback_rerun); 0 = A/B, tests
     int fb_rerun_fused = 0xC;       // exact re-run of FEW pairs (<= kRerunTwoKernelMax): level mask of the fused kernel (bit 3 = 40 px must be set), the other levels run the two-kernel path
     int last_rerun = 0;             // pairs re-run by the last drained call

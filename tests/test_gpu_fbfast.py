@@ -350,34 +350,3 @@ def test_the_160_px_shape_follows_what_is_in_flight(oracle):
         assert np.array_equal(alone, shared) and np.array_equal(rec, alone)
         again = b.analyze_frames(clip)
         assert b.get_option("fb_wide160_used") == 0 and np.array_equal(again, alone)
-
-
-def test_r1_window_in_lds_is_bit_identical(oracle):
-    """fb_win (default 1): the 320-px level's second and third launch take the bilinear samples of R1 from an LDS window of R1 rows that the chain waves stream in
-    (waves whose 64 warped positions all lie inside it) or from memory (any position outside: flows beyond [-2, +3) px vertically) -- the same values
-    either way.  Smooth clips (inside), big shifts and white noise (outside, mixed), the hard set, first / last rows and columns: every level's flow bit for bit."""
-    import avd_hip
-    from tests.content_families import families
-    fam = families()
-    rng = np.random.default_rng(77)
-    mixed = []
-    for name in ("smooth_shift", "smooth_big_shift", "zoom_rot", "white_noise", "letterbox", "pink_shift", "scene_cut", "half_flat"):
-        a, b = fam[name](rng)
-        mixed += [a, b]
-    sets = [_smalls(oracle, synth.make_clip(6, 360, 640, seed=41, dup_every=3)), np.stack(mixed), _hard_frames()]
-    with avd_hip.Context(0) as c:
-        c.set_option("fb_mode", 1)
-        c.set_option("fb_rerun", 0)                        # the fast kernels themselves, on every pair
-        assert c.get_option("fb_win") == 1
-        for si, frames in enumerate(sets):
-            c.set_option("fb_win", 0)
-            fm0, fv0, flow0 = c.farneback_pairs(frames, want_flow=True)
-            c.set_option("fb_win", 1)
-            fm1, fv1, flow1 = c.farneback_pairs(frames, want_flow=True)
-            assert np.array_equal(flow0.view(np.uint32), flow1.view(np.uint32)), (si, int(np.count_nonzero(flow0.view(np.uint32) != flow1.view(np.uint32))))
-            assert np.array_equal(fm0, fm1) and np.array_equal(fv0, fv1), si
-            for fold in (0, 4):                            # also with the first launch reading a written flow (no chain-wave resize): all three launches use the window
-                c.set_option("fb_fold_up", fold)
-                _, _, flow2 = c.farneback_pairs(frames, want_flow=True)
-                assert np.array_equal(flow0.view(np.uint32), flow2.view(np.uint32)), (si, fold)
-            c.set_option("fb_fold_up", 5)
