@@ -137,7 +137,11 @@ def _verbose_sample(b):
             "cpu_baseline": {"value": 453.0, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "s" * 200, "single_thread_value": 30.7,
                              "process_ladder": [{"procs": 16, "frames_per_s": 453.0}] * 4, "cores_usable_how": "cgroup CPU quota 16"},
             "fb_modes": {"value_uses": "fast+rerun", "rerun_pairs": 0, "guarantee": "g" * 200, "exact_frames_per_s": 110000.0, "exact_level320_ms": 0.84,
-                         "fast": {"what": note}, "exact": {"what": note, "roofline": dict(dom)}},
+                         "fast": {"what": note}, "exact": {"what": note, "roofline": dict(dom)},
+                         "rerun_cost": {"content": note, "how": note, "unflagged_sec_per_video_resident": 0.00111, "exact_mode_sec_per_video_resident": 0.0023,
+                                        "exact_mode_frames_per_s": 110000.0,
+                                        "cases": [{"pairs_replaced": n, "pairs_flagged": n, "sec_per_video_resident": 0.0018, "added_ms": 0.68,
+                                                   "frames_per_s": 104000.0, "note": note} for n in (1, 12, 119)]}},
             "mfma_patch_embed": {"kernel": note, "bound": "mfma", "achieved": 880.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.35, "avg_launch_ms": 0.25},
             "mfma_cnn_forward": {"kernel": note, "bound": "mfma", "achieved": 407.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.163, "forward_ms": 2.4,
                                  "hbm_traffic_bytes_per_forward": 7_610_000_000, "hbm_note": note},
@@ -176,6 +180,10 @@ def test_the_printed_line_is_compact_and_keeps_what_the_driver_reads():
     assert abs(lvl["frac"] - r["frac"]) < 0.01                       # the dominant kernel's row agrees with the roofline object
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 16 and "process_ladder" not in line["cpu_baseline"]
     assert line["fb_modes"]["rerun_pairs"] == 0 and line["config"]["workload"].startswith("BASELINE.json configs[1]")
+    rc = line["fb_modes"]["rerun_cost"]                              # what a flagged pair costs is in the driver's line
+    assert [c["pairs_flagged"] for c in rc["cases"]] == [1, 12, 119] and all(set(c) == {"pairs_flagged", "sec_per_video_resident", "added_ms", "frames_per_s"}
+                                                                              for c in rc["cases"])
+    assert rc["unflagged_sec_per_video_resident"] == 0.00111 and rc["exact_mode_frames_per_s"] == 110000.0 and "content" not in rc
     assert line["extensions"]["patch_embed"]["frac"] == 0.35 and "kernel" not in line["extensions"]["patch_embed"]
     # N > 1: no cpu_baseline (rank 0 at N = 1 only), the roofline stays
     full["cpu_baseline"] = None
