@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstring>
 #include <new>
+#include <thread>
 #include "avd_internal.h"
 
 namespace {
@@ -332,10 +333,12 @@ static void launch_records(avd_ctx* ctx, int p0, int np, int fa, const int* clip
 // (nothing is launched when nothing is flagged -- the usual case).  For the last chunk of an asynchronous call that happens when the call is
 // drained (ctx->tail, impl_synchronize): the flags travel with the records.  A chunk that is followed by another one (> 512 pairs in a call), and
 // every chunk of a call that hands statistics straight to the host, is settled here, before its scratch is reused.
+static void tail_unregister(avd_ctx* ctx);
 static int run_flow_chunks(avd_ctx* ctx, const uint8_t* d_small, int n, float* h_mean, float* h_var,
                            float* h_flow_out, bool into_records, const int* records_clipstart = nullptr)
 {
     Workspace& ws = ctx->ws;
+    tail_unregister(ctx);
     ctx->tail.active = 0;
     if (n < 2) return 0;
     if (int e = avd_ws_reserve_fb(ctx, n)) return e;
@@ -417,6 +420,93 @@ static void stage_mark(avd_ctx* ctx, int i)
 std::atomic<int> g_calls_in_flight{0};
 int avd_calls_in_flight() { return g_calls_in_flight.load(std::memory_order_relaxed); }
 
+// ---- contexts whose last Farneback chunk awaits its flags (fast mode; ctx->tail) ---------------------------------------------------------
+// The exact re-run of a call's flagged pairs needs the HOST (it reads the flag words and sizes the launches).  With one host thread driving
+// several contexts in turn, each clip's re-run would start only when the thread reaches that clip's avd_synchronize: the chip sits on one
+// re-run chain at a time (a fully flagged 120-frame clip: 76 k frames/s against 108 k with one thread per context).  So a thread that has to wait
+// anyway -- for its own fast pass or its own re-run -- looks at the other registered contexts of its device and settles those whose records have
+// arrived.  Lock order: ctx->api_mu (blocking, taken by every entry point) -> g_tail_mu -> another context's api_mu (try_lock only).
+static std::mutex g_tail_mu;
+static std::vector<avd_ctx*> g_tail_list;
+static std::atomic<int> g_tail_count{0};
+
+static void tail_register(avd_ctx* ctx)
+{
+    if (ctx->tail_registered || hipEventRecord(ctx->tail_ev, ctx->stream) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    g_tail_list.push_back(ctx);
+    ctx->tail_registered = 1;
+    g_tail_count.fetch_add(1, std::memory_order_relaxed);
+}
+
+static void tail_unregister(avd_ctx* ctx)
+{
+    if (!ctx->tail_registered) return;
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    for (size_t i = 0; i < g_tail_list.size(); i++)
+        if (g_tail_list[i] == ctx) { g_tail_list[i] = g_tail_list.back(); g_tail_list.pop_back(); break; }
+    ctx->tail_registered = 0;
+    g_tail_count.fetch_sub(1, std::memory_order_relaxed);
+}
+
+// The records of ctx's last chunk (with the level kernels' flag words) are in the pinned buffer: the pairs they mark go through the exact kernels
+// (the workspace still holds the chunk), the chunk's records are assembled again and fetched.  Enqueues only; the caller holds ctx->api_mu.
+static int tail_settle(avd_ctx* ctx)
+{
+    ctx->tail.active = 0;
+    Workspace& ws = ctx->ws;
+    const int p0 = ctx->tail.p0, np = ctx->tail.np, fa = ctx->tail.fa;
+    const int m = rerun_flagged(ctx, &ws.h_rec[p0 + 1].reserved, (int)(sizeof(avd_frame_record) / sizeof(int)), np);
+    if (m < 0) return m;
+    if (m > 0) {
+        launch_records(ctx, p0, np, fa, ctx->tail.clipstart);
+        HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec + fa, ws.d_rec + fa, sizeof(avd_frame_record) * (size_t)(p0 + np + 1 - fa), hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->profiling && ctx->kmark_used > 0) kmark(ctx, AVD_K_COUNT);     // close the re-run's region
+    }
+    return AVD_OK;
+}
+
+static void tail_help_others(avd_ctx* self)
+{
+    if (g_tail_count.load(std::memory_order_relaxed) == 0) return;
+    std::unique_lock<std::mutex> lk(g_tail_mu, std::try_to_lock);
+    if (!lk.owns_lock()) return;
+    for (size_t i = 0; i < g_tail_list.size();) {
+        avd_ctx* c = g_tail_list[i];
+        if (c == self || c->device != self->device || !c->api_mu.try_lock()) { i++; continue; }
+        bool settled = !c->tail.active;
+        if (!settled && hipEventQuery(c->tail_ev) == hipSuccess) {
+            int rc;
+            try { rc = tail_settle(c); } catch (...) { c->err = "out of host memory"; rc = AVD_ERR_NOMEM; }
+            c->tail.active = 0;
+            c->tail_rc = rc;
+            settled = true;
+        }
+        if (settled) {
+            g_tail_list[i] = g_tail_list.back(); g_tail_list.pop_back();
+            c->tail_registered = 0;
+            g_tail_count.fetch_sub(1, std::memory_order_relaxed);
+        } else {
+            i++;
+        }
+        c->api_mu.unlock();
+    }
+}
+
+// Wait for `ev` (or, with ev == nullptr, for everything on the context's stream).  While other contexts hold unsettled tails the wait is a poll
+// that settles them as their fast passes finish; otherwise it blocks in the runtime.
+static hipError_t wait_helping(avd_ctx* ctx, hipEvent_t ev)
+{
+    int spins = 0;
+    while (ctx->tail_help && g_tail_count.load(std::memory_order_relaxed) - ctx->tail_registered > 0) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(ctx->stream);
+        if (e != hipErrorNotReady) return e;
+        tail_help_others(ctx);
+        if (++spins > 64) std::this_thread::yield();
+    }
+    return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(ctx->stream);
+}
+
 // ---- entry-point bodies (wrapped by the extern "C" functions at the end of the file) -----------------
 static void impl_destroy(avd_ctx* ctx);
 static int impl_synchronize(avd_ctx* ctx);
@@ -435,7 +525,8 @@ static int impl_create(int device_id, avd_ctx** out)
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&ctx->stage_ev[i]) == hipSuccess;
     for (int i = 0; ok && i < 12; i++) ok = hipEventCreate(&ctx->kern_ev[i]) == hipSuccess;
     if (ok) {
@@ -461,6 +552,8 @@ static int impl_create(int device_id, avd_ctx** out)
 static void impl_destroy(avd_ctx* ctx)
 {
     if (!ctx) return;
+    tail_unregister(ctx);                                   // no helper finds the context from here on ...
+    { std::lock_guard<std::recursive_mutex> lk(ctx->api_mu); }   // ... and one that had found it has let go
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->counted_in_flight) { ctx->counted_in_flight = 0; g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -470,6 +563,7 @@ static void impl_destroy(avd_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+    if (ctx->tail_ev) (void)hipEventDestroy(ctx->tail_ev);
     for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kern_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->kmark_ev) if (e) (void)hipEventDestroy(e);
@@ -668,6 +762,7 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
     // the whole call is done and it would not be asynchronous at all; avd_synchronize hands the records over
     HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec, ws.d_rec, sizeof(avd_frame_record) * n, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pending_out = records; ctx->pending_n = n;
+    if (ctx->tail.active) tail_register(ctx);              // from here on a waiting thread may settle this call's tail
     if (!ctx->counted_in_flight) { ctx->counted_in_flight = 1; g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
     kmark(ctx, AVD_K_COUNT);                               // end of the last region
     stage_mark(ctx, 4);
@@ -755,22 +850,21 @@ static int impl_synchronize(avd_ctx* ctx)
         avd_ctx* c;
         ~Uncount() { if (c->counted_in_flight) { c->counted_in_flight = 0; g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); } }
     } uncount{ctx};
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->tail.active) {
-        // fast Farneback mode: the records of the call's last chunk carry the level kernels' flag words; the pairs they mark go through the
-        // exact kernels now (the workspace still holds the chunk), the chunk's records are assembled again and fetched
-        ctx->tail.active = 0;
-        Workspace& ws = ctx->ws;
-        const int p0 = ctx->tail.p0, np = ctx->tail.np, fa = ctx->tail.fa;
-        const int m = rerun_flagged(ctx, &ws.h_rec[p0 + 1].reserved, (int)(sizeof(avd_frame_record) / sizeof(int)), np);
-        if (m < 0) return m;
-        if (m > 0) {
-            launch_records(ctx, p0, np, fa, ctx->tail.clipstart);
-            HIP_TRY(ctx, hipMemcpyAsync(ws.h_rec + fa, ws.d_rec + fa, sizeof(avd_frame_record) * (size_t)(p0 + np + 1 - fa), hipMemcpyDeviceToHost, ctx->stream));
-            if (ctx->profiling && ctx->kmark_used > 0) kmark(ctx, AVD_K_COUNT);     // close the re-run's region
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        }
+        // fast Farneback mode: the records of the call's last chunk carry the level kernels' flag words (tail_settle) -- unless a thread that
+        // was waiting for its own context has settled this one already
+        const hipError_t e = ctx->tail_registered ? wait_helping(ctx, ctx->tail_ev) : hipStreamSynchronize(ctx->stream);
+        tail_unregister(ctx);
+        if (e != hipSuccess) { ctx->tail.active = 0; ctx->pending_out = nullptr; ctx->pending_n = 0; ctx->err = hipGetErrorString(e); return AVD_ERR_DEVICE; }
+        if (ctx->tail.active) ctx->tail_rc = tail_settle(ctx);
     }
+    if (ctx->tail_rc) {                                     // the re-run could not be enqueued (by this thread or by a helper): the call has failed
+        const int rc = ctx->tail_rc;
+        ctx->tail_rc = 0; ctx->pending_out = nullptr; ctx->pending_n = 0;
+        return rc;
+    }
+    HIP_TRY(ctx, wait_helping(ctx, nullptr));
     if (ctx->pending_out) {
         std::memcpy(ctx->pending_out, ctx->ws.h_rec, sizeof(avd_frame_record) * ctx->pending_n);
         ctx->last_rerun = 0;
@@ -915,6 +1009,7 @@ static int impl_set_option(avd_ctx* ctx, const char* name, int value)
     if (std::strcmp(name, "fb_fold_up") == 0) { ctx->fb_fold_up = value & 7; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { ctx->fb_rerun = value ? 1 : 0; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun_fused") == 0) { ctx->fb_rerun_fused = (value & 0xF) | 8; return AVD_OK; }
+    if (std::strcmp(name, "tail_help") == 0) { ctx->tail_help = value != 0; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { ctx->fb_wide160 = value == 0 ? 0 : (value == 1 ? 1 : 2); return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { ctx->fb_fold_blur = value != 0; return AVD_OK; }
     if (std::strcmp(name, "gemm_waves") == 0) { ctx->gemm_waves = value == 16 ? 16 : 8; return AVD_OK; }
@@ -939,6 +1034,7 @@ static int impl_get_option(avd_ctx* ctx, const char* name, int* value)
     if (std::strcmp(name, "fb_fold_up") == 0) { *value = ctx->fb_fold_up; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun") == 0) { *value = ctx->fb_rerun; return AVD_OK; }
     if (std::strcmp(name, "fb_rerun_fused") == 0) { *value = ctx->fb_rerun_fused; return AVD_OK; }
+    if (std::strcmp(name, "tail_help") == 0) { *value = ctx->tail_help; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160") == 0) { *value = ctx->fb_wide160; return AVD_OK; }
     if (std::strcmp(name, "fb_wide160_used") == 0) { *value = ctx->fb_wide160_used; return AVD_OK; }
     if (std::strcmp(name, "fb_fold_blur") == 0) { *value = ctx->fb_fold_blur; return AVD_OK; }
@@ -1157,6 +1253,8 @@ template <typename F>
 static int guarded(avd_ctx* ctx, F&& f) noexcept
 {
     try {
+        if (!ctx) return f();
+        std::lock_guard<std::recursive_mutex> lk(ctx->api_mu);     // one call at a time per context; helpers of other contexts only try_lock (tail_help_others)
         return f();
     } catch (const std::bad_alloc&) {
         if (ctx) { try { ctx->err = "out of host memory"; } catch (...) {} }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/avd.h"
@@ -203,6 +204,13 @@ struct avd_ctx {
     int last_rerun = 0;             // pairs re-run by the last drained call
     // the last Farneback chunk of an asynchronous call, whose flags the host has not seen yet (impl_synchronize re-runs its flagged pairs)
     struct { int active = 0, p0 = 0, np = 0, fa = 0, n = 0; const int* clipstart = nullptr; } tail;
+    // A thread that waits in avd_synchronize settles the tails of OTHER contexts whose fast pass has finished meanwhile (avd_capi.hip, tail_help_others):
+    // one host thread driving several contexts (avd_hip.ClipsInFlight, bench.py) would otherwise start each clip's re-run only when it reaches that clip.
+    std::recursive_mutex api_mu;    // held by every entry point that takes this context; helpers only try_lock it
+    hipEvent_t tail_ev = nullptr;   // the call's records (with the flag words) have reached the pinned buffer
+    int tail_registered = 0;        // in the process-wide list of contexts with an unsettled tail
+    int tail_rc = 0;                // status of a settlement another thread did for this context (reported by its avd_synchronize)
+    int tail_help = 1;              // option "tail_help": 0 = never settle other contexts' tails, wait with hipStreamSynchronize (A/B, tests)
 };
 
 // profiling only (avd_set_profiling): the region that starts here on the context's stream is kernel `id`

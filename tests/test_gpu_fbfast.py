@@ -350,3 +350,66 @@ def test_the_160_px_shape_follows_what_is_in_flight(oracle):
         assert np.array_equal(alone, shared) and np.array_equal(rec, alone)
         again = b.analyze_frames(clip)
         assert b.get_option("fb_wide160_used") == 0 and np.array_equal(again, alone)
+
+
+def test_a_waiting_thread_settles_the_other_contexts_tails():
+    """One host thread, several contexts in flight (avd_hip.ClipsInFlight, bench.py): while it waits in avd_synchronize of one context it sends
+    the flagged pairs of the OTHERS through the exact kernels as their fast passes finish (avd_capi.hip, tail_help_others).  Who settles a call
+    changes nothing: records identical to the same clips analysed one at a time, with the helper off (option tail_help = 0) and with one thread
+    per context; clips of different length and flag density, drained in and out of submission order, many rounds."""
+    import threading
+    import avd_hip
+    clips = [np.repeat(_flagged_mix(n, seed)[..., None], 3, axis=3) for n, seed in ((40, 21), (9, 22), (64, 23), (3, 24))]
+    clips.append(np.repeat(_flagged_mix(30, 25)[::2][..., None], 3, axis=3))
+    with avd_hip.Context(0) as c:
+        c.set_option("tail_help", 0)
+        want = [c.analyze_frames(k).copy() for k in clips]
+    assert sum(int((w["reserved"] != 0).sum()) for w in want) >= 40 and all((w["reserved"] != 0).any() for w in want)
+    ctxs = [avd_hip.Context(0) for _ in range(4)]
+    try:
+        assert all(c.get_option("tail_help") == 1 for c in ctxs)
+        for help_on in (1, 0):
+            for c in ctxs:
+                c.set_option("tail_help", help_on)
+            for rnd in range(6):
+                order = [(rnd + j) % len(clips) for j in range(len(ctxs))]
+                recs = [np.zeros(len(clips[k]), avd_hip.RECORD_DTYPE) for k in order]
+                for j, k in enumerate(order):
+                    ctxs[j].analyze_frames_async(clips[k], recs[j])
+                drain = list(range(len(ctxs))) if rnd % 2 == 0 else list(reversed(range(len(ctxs))))
+                for j in drain:
+                    ctxs[j].synchronize()
+                    assert ctxs[j].get_option("rerun_pairs") == int((want[order[j]]["reserved"] != 0).sum())
+                for j, k in enumerate(order):
+                    assert recs[j].tobytes() == want[k].tobytes(), (help_on, rnd, j, k)
+        # one thread per context, all of them helping each other
+        for c in ctxs:
+            c.set_option("tail_help", 1)
+        bad = []
+
+        def work(j):
+            rec = np.zeros(max(len(k) for k in clips), avd_hip.RECORD_DTYPE)
+            for i in range(8):
+                k = (i + j) % len(clips)
+                r = rec[:len(clips[k])]
+                ctxs[j].analyze_frames_async(clips[k], r)
+                ctxs[j].synchronize()
+                if r.tobytes() != want[k].tobytes():
+                    bad.append((j, i, k))
+        ths = [threading.Thread(target=work, args=(j,)) for j in range(len(ctxs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not bad, bad
+        # a context destroyed with an unsettled tail, while another one waits
+        extra = avd_hip.Context(0)
+        r0, r1 = np.zeros(len(clips[0]), avd_hip.RECORD_DTYPE), np.zeros(len(clips[2]), avd_hip.RECORD_DTYPE)
+        extra.analyze_frames_async(clips[0], r0)
+        ctxs[0].analyze_frames_async(clips[2], r1)
+        extra.close()
+        ctxs[0].synchronize()
+        assert r1.tobytes() == want[2].tobytes()
+    finally:
+        for c in ctxs:
+            c.close()
