@@ -47,10 +47,11 @@ def main():
     ctxs = [avd_hip.Context(0) for _ in range(6)]
     recs = [np.zeros(n, avd_hip.RECORD_DTYPE) for _ in range(6)]
     try:
-        for pairs, helping in ((0, 1), (0, 0), (1, 1), (1, 0), (12, 1), (12, 0), (n - 1, 1), (n - 1, 0)):
+        for pairs, helping in ((0, 1), (1, 1), (12, 1), (n - 1, 1)):     # 2: re-run off (what the content alone costs the fast pass)
             v = variant(pairs) if pairs else base
             for c in ctxs:
-                c.set_option("tail_help", helping)
+                c.set_option("tail_help", helping & 1)
+                c.set_option("fb_rerun", 0 if helping == 2 else 1)
             for j in range(6):
                 ctxs[j].analyze_frames_async(v, recs[j]); ctxs[j].synchronize()
             bits = {}
@@ -58,7 +59,7 @@ def main():
                 if r:
                     bits[int(r)] = bits.get(int(r), 0) + 1
             out = []
-            for m in (1, 2, 3, 4):
+            for m in (2, 3, 4, 5, 6):
                 thr = []
                 for _ in range(3):
                     torch.cuda.synchronize()
@@ -73,7 +74,7 @@ def main():
                         ctxs[q.pop(0)].synchronize()
                     thr.append(steps * n / (time.perf_counter() - t1))
                 out.append(f"m={m}: {statistics.median(thr) / 1e3:6.1f} k")
-            for m in (3,):                       # one host thread per context (what a pool of borrowers does): each loops submit + drain on its own
+            for m in (3, 4, 6):                       # one host thread per context (what a pool of borrowers does): each loops submit + drain on its own
                 thr = []
                 for _ in range(3):
                     torch.cuda.synchronize()
