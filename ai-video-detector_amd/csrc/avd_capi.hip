@@ -441,8 +441,8 @@ static void tail_register(avd_ctx* ctx)
 
 static void tail_unregister(avd_ctx* ctx)
 {
+    std::lock_guard<std::mutex> lk(g_tail_mu);             // a helper writes tail_registered under this lock
     if (!ctx->tail_registered) return;
-    std::lock_guard<std::mutex> lk(g_tail_mu);
     for (size_t i = 0; i < g_tail_list.size(); i++)
         if (g_tail_list[i] == ctx) { g_tail_list[i] = g_tail_list.back(); g_tail_list.pop_back(); break; }
     ctx->tail_registered = 0;
