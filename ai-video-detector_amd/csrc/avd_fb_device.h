@@ -59,12 +59,25 @@ __device__ __forceinline__ void st_off_nt(void* __restrict__ base, unsigned byte
     __builtin_nontemporal_store(v, reinterpret_cast<T*>(static_cast<char*>(base) + byte_off));
 }
 
+template <bool SCALAR_ROW = false>
 __device__ __forceinline__ void ne_load(const float* __restrict__ R, const float* __restrict__ flow, unsigned r0base,
                                         unsigned flbase, int x, int y, int w, int plane, NeIn& in)
 {
-    const unsigned o = (unsigned)(y * w + x);
-    in.dx = ld_off<float>(flow, (flbase + o) * 4u); in.dy = ld_off<float>(flow, (flbase + plane + o) * 4u);
-    const unsigned pb = (r0base + o * 5u) * 4u;
+    unsigned pb;
+    if constexpr (!SCALAR_ROW) {
+        const unsigned o = (unsigned)(y * w + x);
+        in.dx = ld_off<float>(flow, (flbase + o) * 4u); in.dy = ld_off<float>(flow, (flbase + plane + o) * 4u);
+        pb = (r0base + o * 5u) * 4u;
+    } else {
+        // the row's part of the offsets is a SCALAR the compiler cannot see through (the 14-wave latency shapes of the fast level kernels, 128
+        // registers): left to itself it turns every one of these loads, in every unrolled step, into a 64-bit per-lane pointer that it advances
+        // and spills (31 registers of the 80-px kernel, reloaded inside the loop); this way a load is "uniform base + (lane part + row part)",
+        // one 32-bit add.  The 12-wave shape of the 320-px level has the registers and is five instructions per step better off without.
+        const unsigned yo = (unsigned)__builtin_amdgcn_readfirstlane(y * w);
+        const unsigned o4 = (yo + (unsigned)x) * 4u;
+        in.dx = ld_off<float>(flow, flbase * 4u + o4); in.dy = ld_off<float>(flow, (flbase + plane) * 4u + o4);
+        pb = r0base * 4u + o4 * 5u;
+    }
     const F4 v = ld_off<F4>(R, pb);
     in.r0[0] = v.a; in.r0[1] = v.b; in.r0[2] = v.c; in.r0[3] = v.d; in.r0[4] = ld_off_i<float, 16>(R, pb);
 }
@@ -322,6 +335,16 @@ __device__ __forceinline__ double recip_exact(double d)
     const double e2 = __builtin_fma(-d, q, 1.);
     return __builtin_fma(e2, r2, q);
 #endif
+}
+
+// the same without the final quotient step: two Newton steps on v_rcp_f64 (relative error ~1e-16 on [1e-3, 1e13]), for the fast level kernels
+__device__ __forceinline__ double recip_newton2(double d)
+{
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e0 = __builtin_fma(-d, r0, 1.);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-d, r1, 1.);
+    return __builtin_fma(r1, e1, r1);
 }
 
 }  // namespace

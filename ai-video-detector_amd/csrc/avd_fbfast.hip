@@ -48,6 +48,12 @@ constexpr int kM = 7;                 // (winsize - 1) / 2
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
+#ifdef AVD_FBF_NO_SCALAR_ROW       // A/B builds (tools/r05_ab_solve.sh)
+constexpr bool kScalarRow = false;
+#else
+constexpr bool kScalarRow = true;
+#endif
+
 // W level size; NB 64-column blocks per strip; GD lead of the bilinear gather; NPB normal-equation waves per block (2: two
 // entries each per step, 4: one each); XPB solver waves per block (1: four columns per lane, 2: two columns per lane).
 // 2 + 1 + 1 waves per block is the throughput shape (320 px: the chip is full and total issue counts); 4 + 1 + 2 is the
@@ -150,7 +156,7 @@ __device__ __forceinline__ bool role_ne(const float* __restrict__ R, const float
     auto flow_of = [&](int row, NeIn& s) { const float* f = fring + (row & 15) * Ge::F_SLOT + lane; s.dx = f[0]; s.dy = f[64]; };
     auto load_in = [&](int row, NeIn& s) {
         if (UP) ne_load_r0(R, r0base, x, row, W, s);
-        else ne_load(R, flow, r0base, flbase, x, row, W, plane, s);
+        else ne_load<Ge::PN && kScalarRow>(R, flow, r0base, flbase, x, row, W, plane, s);
     };
     bool first = skip != nullptr;                          // the first barrier of this role has not been passed yet
     if (UP) {
@@ -383,7 +389,7 @@ __device__ __forceinline__ bool role_solve(const double* __restrict__ vsring, fl
     const long long fbf_t0 = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int W = Ge::W, H = W, plane = W * H, CPL = Ge::CPL, NV = 14 + CPL;
-    const double scale = 1. / (15 * 15);
+    [[maybe_unused]] const double scale = 1. / (15 * 15);
     const int r = lane >> 4, j = 16 * (Ge::XPB * b + xi) + (lane & 15);      // chunk of CPL columns: output columns CPL j ..
     const bool colok = CPL * j < ow;
     float* fl = flow_out + (size_t)p * 2 * plane + o0 + CPL * j;
@@ -421,11 +427,20 @@ __device__ __forceinline__ bool role_solve(const double* __restrict__ vsring, fl
                         double A = v[3];
 #pragma unroll
                         for (int i = 4; i < 15; i++) A += v[i];
+#ifdef AVD_FBF_SOLVE_R4
                         const double p12 = v[1] + v[2], q2 = v[15] + v[16];
                         o[c][0] = A + (v[0] + p12);
                         o[c][1] = A + (p12 + v[15]);
                         o[c][2] = A + (v[2] + q2);
                         o[c][CPL - 1] = A + (q2 + v[NV - 1]);
+#else
+                        // four windows of fifteen from eighteen values in 19 additions: the twelve they share, then the two pairs next to them
+                        const double Bl = A + (v[1] + v[2]), Br = A + (v[15] + v[16]);
+                        o[c][0] = Bl + v[0];
+                        o[c][1] = Bl + v[15];
+                        o[c][2] = Br + v[2];
+                        o[c][CPL - 1] = Br + v[NV - 1];
+#endif
                     } else {
                         double A = v[1];
 #pragma unroll
@@ -437,6 +452,7 @@ __device__ __forceinline__ bool role_solve(const double* __restrict__ vsring, fl
                 float fx[CPL], fy[CPL];
 #pragma unroll
                 for (int i = 0; i < CPL; i++) {
+#ifdef AVD_FBF_SOLVE_R4
                     const double g11 = o[0][i] * scale, g12 = o[1][i] * scale, g22 = o[2][i] * scale;
                     const double h1 = o[3][i] * scale, h2 = o[4][i] * scale;
                     const double t1 = g11 * g22, t2 = g12 * g12, den = t1 - t2 + 1e-3;      // cv2's determinant, its operation order
@@ -444,6 +460,19 @@ __device__ __forceinline__ bool role_solve(const double* __restrict__ vsring, fl
                     fx[i] = (float)((g11 * h2 - g12 * h1) * idet);
                     fy[i] = (float)((g22 * h1 - g12 * h2) * idet);
                     ill |= !(t1 + t2 <= kCondMax * den) | !(fmaxf(fabsf(fx[i]), fabsf(fy[i])) <= kFlowMax * (float)W);
+#else
+                    // cv2 scales the five sums by 1 / 225 and adds 1e-3 to the determinant; the scale cancels in the quotient, so the sums stay as
+                    // they are and the 1e-3 becomes 1e-3 * 225^2 (round 5: 14 double operations per column instead of 28; this mode's flow is held
+                    // to a tolerance, not to cv2's rounding -- the exact kernels keep cv2's order).  The criterion t1 + t2 <= kCondMax den with
+                    // t1 = den - c + t2 reads t2 <= (kCondMax - 1) / 2 den + c / 2.
+                    constexpr double kC = 1e-3 * 225. * 225.;
+                    const double a = o[0][i], b = o[1][i], d = o[2][i], h1 = o[3][i], h2 = o[4][i];
+                    const double t2 = b * b, den = __builtin_fma(a, d, kC - t2);
+                    const double idet = recip_newton2(den);
+                    fx[i] = (float)(__builtin_fma(a, h2, -(b * h1)) * idet);
+                    fy[i] = (float)(__builtin_fma(d, h1, -(b * h2)) * idet);
+                    ill |= !(t2 <= __builtin_fma(0.5 * (kCondMax - 1.), den, 0.5 * kC)) | !(fmaxf(fabsf(fx[i]), fabsf(fy[i])) <= kFlowMax * (float)W);
+#endif
                 }
                 // last iteration of the 320-px level: |flow| as np.sqrt(fx * fx + fy * fy) forms it in float32 (video.py:46), for the
                 // statistics kernels -- they then read 4 bytes per pixel twice instead of 8, and the flow only once, here

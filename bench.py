@@ -938,10 +938,12 @@ def main():
                 ops_t = (v["f32_ops_per_level"] + v["f64_ops_per_level"]) / t_lvl / 1e12 if t_lvl > 0 else 0.0
                 dominant.update({"bound": "valu", "achieved": round(ops_t, 2), "peak": round(ops_t / v["frac_of_vector_peak"], 2),
                                  "unit": "Top/s", "frac": v["frac_of_vector_peak"]})
-            dominant["limiter"] = ("vector-ALU issue on the three SIMDs of a workgroup that carry a solver wave: per 4-row step X (window sums + 2 x 2 solve in "
-                                   "double: 213 f64 + 97 f32 instructions) + one normal-equation wave (140 f32) + the chain wave (89 f32 + 35 f64) = ~3 260 busy "
-                                   "cycles = the measured step time (84 steps per launch); the fourth SIMD (three normal-equation waves) is half idle and no "
-                                   "assignment of whole waves balances it; texture addresser 0.53 busy beside it (PMC)")
+            dominant["limiter"] = ("two co-limiters that do not overlap, and a workgroup barrier per 4-row step: vector-ALU issue on the three SIMDs that carry a "
+                                   "solver wave -- per step X (window sums + 2 x 2 solve in double: 159 f64 + 100 f32 instructions, 849 cycles) + one normal-equation "
+                                   "wave (168 f32 + 20 loads, 335) + the chain wave (89 f32 + 35 f64, 307) = ~1 490 of the ~3 200 cycles a step takes (84 steps per launch; "
+                                   "PMC: VALU issue 0.54 chip-wide) -- and the texture addresser (129 vector-memory instructions x 16 cycles per step = 0.65; PMC 0.53); "
+                                   "the normal-equation waves are both the loads' only issuers and the second-largest VALU consumer "
+                                   "(tools/isa_loop_table.py, profiles/r05_isa_k_fb_fast320.txt)")
         else:
             dominant["limiter"] = "the dependent double-add chain of the horizontal scan + VALU issue of the vertical waves, one workgroup per pair on 119 of 256 CUs"
         dominant["kernels"] = kernel_table(n, h, w, kms, None if nv12 is None else nv12["pre_ms"])
