@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: the fast level kernels' solve with the scale folded out (14 instead of 28 double operations per column, 19 instead of 21 additions per four windows)
 # and the latency shapes' input loads with a scalar row offset (no spills in the 80-px kernel), each against the kernels before, alternating on ONE box.
-# ai-video-detector_amd/lib_ab/{A,B,C,D}.so: A = before (-DAVD_FBF_SOLVE_R4 -DAVD_FBF_NO_SCALAR_ROW), B = both, C = solve only, D = loads only.
+# ai-video-detector_amd/lib_ab/{A,B,C,D}.so (make -C ai-video-detector_amd/csrc -B OUT=../lib_ab/X.so EXTRA="..."): A = before (-DAVD_FBF_SOLVE_R4 -DAVD_FBF_NO_SCALAR_ROW), B = both, C = solve only, D = loads only.
 cd "$(dirname "$0")/.."
 L=ai-video-detector_amd/lib
 for i in 1 2 3; do
