@@ -27,4 +27,4 @@ python bench.py --inflight 1 --cpu-frames 0 --no-extras --no-vit --details gpuru
 AVD_BENCH_DEVICE=0 python bench.py --gpus 2 --backend gloo --cpu-frames 0 --no-extras --no-vit --no-pcie --repeats 3 > gpurun_out/r05_rehearsal_2ranks_1gpu_gloo.json 2> gpurun_out/r05_rehearsal.err || echo "rehearsal failed"
 echo "stdout lines of the 2-rank rehearsal: $(wc -l < gpurun_out/r05_rehearsal_2ranks_1gpu_gloo.json)"
 head -c 400 gpurun_out/r05_bench.json; echo
-for t in kt1 kt3 kt1_exact; do echo "== $t"; find gpurun_out/r05_$t -name "*kernel_stats.csv" | head -1 | xargs -I{} python tools/kstats.py {} 7 18; done
+for t in kt1 kt3 kt1_exact; do echo "== $t"; ls -t $(find gpurun_out/r05_$t -name "*kernel_stats.csv") | head -1 | xargs -I{} python tools/kstats.py {} 7 18    # the NEWEST: gpurun_out/ accumulates earlier runs; done
