@@ -492,6 +492,22 @@ __device__ __forceinline__ ChromaTerms chroma_terms(int U, int V, const YuvConst
     return t;
 }
 
+// the table form: the three indices' chroma parts (libswscale's per-U / per-V table offsets), biased so that Y + offset >= 0
+constexpr int kNvBias = 224, kNvTab = 704;     // Y + offset in [-221, 475]
+__device__ __forceinline__ ChromaTerms chroma_offsets(int U, int V, const YuvConsts& k)
+{
+    ChromaTerms t;
+    t.r = (__mul24(V, k.crv) >> 16) + (k.kr + kNvBias);
+    t.b = (__mul24(U, k.cbu) >> 16) + (k.kb + kNvBias);
+    t.g = (__mul24(U, k.cgu) >> 16) + (__mul24(V, k.cgv) >> 16) + (k.kg + kNvBias);
+    return t;
+}
+
+__device__ __forceinline__ unsigned gray_from_tables(int Y, const ChromaTerms& t, const unsigned* tabB, const unsigned* tabG, const unsigned* tabR)
+{
+    return (tabB[Y + t.b] + tabG[Y + t.g] + tabR[Y + t.r]) >> 15;
+}
+
 __device__ __forceinline__ unsigned gray_from_yuv(int Y, const ChromaTerms& t, int cy)
 {
     // Y * cy + term: one v_mad_i32_i24 per channel
@@ -528,6 +544,20 @@ __global__ __launch_bounds__(kThreads) void k_preprocess_nv12(const uint8_t* __r
     const uint8_t* cfr = nv.uv + (int64_t)f * nv.uv_frame_stride;
     const int trows = rows + 2;                            // tile row 0 = image row r0-1
     if (VEC) {
+#ifndef AVD_NV12_ARITH
+        // libswscale's converter IS a table lookup: B = T[Y + ob(U)], G = T[Y + og(U, V)], R = T[Y + or(V)] with one clip table T(i) = clip8((c0 + i cy) >> 16).
+        // Round 5: three LDS tables of cv2's gray weight times T (3735 T, 19235 T + the rounding 2^14, 9798 T; 32-bit entries, index bias kNvBias), so a pixel is
+        // three index additions, three ds_read_b32, one three-operand add and a shift -- instead of three multiply-adds, three shifts, three clamps and
+        // three multiply-adds (12.3 -> 8.8 vector instructions per pixel; the LDS pipe does the lookups beside them).  Same integers by construction.
+        unsigned* const tabB = reinterpret_cast<unsigned*>(tile + ((size_t)trows * pitch + 15) / 16 * 16);
+        unsigned* const tabG = tabB + kNvTab;
+        unsigned* const tabR = tabG + kNvTab;
+        for (int i = tid; i < kNvTab; i += kThreads) {
+            const unsigned v = (unsigned)clip8((nv.k.c0 + (i - kNvBias) * nv.k.cy) >> 16);
+            tabB[i] = v * 3735u; tabG[i] = v * 19235u + (1u << 14); tabR[i] = v * 9798u;
+        }
+        __syncthreads();
+#endif
         // one work item = one chroma row x one 16-pixel chunk: the eight chroma-term triples are formed once and serve the
         // two luma rows that share them (they are 8.5 of the ~27 integer operations a pixel costs otherwise)
         const int ylo = r0 - 1, yhi = r0 + rows;              // image rows of tile rows 0 and trows - 1, before reflection
@@ -541,8 +571,13 @@ __global__ __launch_bounds__(kThreads) void k_preprocess_nv12(const uint8_t* __r
             ChromaTerms t[8];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+#ifndef AVD_NV12_ARITH
+                t[2 * j] = chroma_offsets(cw[j] & 0xFF, (cw[j] >> 8) & 0xFF, nv.k);
+                t[2 * j + 1] = chroma_offsets((cw[j] >> 16) & 0xFF, cw[j] >> 24, nv.k);
+#else
                 t[2 * j] = chroma_terms(cw[j] & 0xFF, (cw[j] >> 8) & 0xFF, nv.k);
                 t[2 * j + 1] = chroma_terms((cw[j] >> 16) & 0xFF, cw[j] >> 24, nv.k);
+#endif
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -555,6 +590,9 @@ __global__ __launch_bounds__(kThreads) void k_preprocess_nv12(const uint8_t* __r
                 for (int j = 0; j < 4; j++)
 #ifdef AVD_NV12_NOCONV      // timing experiment: no conversion arithmetic (results are wrong)
                     g[j] = yw[j] ^ cw[j];
+#elif !defined(AVD_NV12_ARITH)
+                    g[j] = gray_from_tables(yw[j] & 0xFF, t[2 * j], tabB, tabG, tabR) | (gray_from_tables((yw[j] >> 8) & 0xFF, t[2 * j], tabB, tabG, tabR) << 8) |
+                           (gray_from_tables((yw[j] >> 16) & 0xFF, t[2 * j + 1], tabB, tabG, tabR) << 16) | (gray_from_tables(yw[j] >> 24, t[2 * j + 1], tabB, tabG, tabR) << 24);
 #else
                     g[j] = gray_from_yuv(yw[j] & 0xFF, t[2 * j], nv.k.cy) | (gray_from_yuv((yw[j] >> 8) & 0xFF, t[2 * j], nv.k.cy) << 8) |
                            (gray_from_yuv((yw[j] >> 16) & 0xFF, t[2 * j + 1], nv.k.cy) << 16) | (gray_from_yuv(yw[j] >> 24, t[2 * j + 1], nv.k.cy) << 24);
@@ -759,7 +797,10 @@ int launch_preprocess_nv12(avd_ctx* ctx, const uint8_t* d_y, const Nv12Params& n
                      (nv.uv_frame_stride % 16 == 0) && (reinterpret_cast<uintptr_t>(d_y) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(nv.uv) % 16 == 0);
     const int grid = ((total + 7) / 8) * 8;
-    const size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
+    size_t lds = (size_t)(P.rows_per_band + 2) * P.pitch;
+#ifndef AVD_NV12_ARITH
+    if (vec) lds = (lds + 15) / 16 * 16 + 3 * sizeof(unsigned) * 704;     // the three conversion tables behind the tile (k_preprocess_nv12, kNvTab)
+#endif
     // (a register-staged variant in the style of k_preprocess_vec measured no faster: the kernel is bound by the
     // conversion's integer arithmetic, not by how its loads are issued -- profiles/r02_experiments.md)
     ws.lap_waves = kThreads / 64;
