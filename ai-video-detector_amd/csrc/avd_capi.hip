@@ -319,6 +319,8 @@ static int rerun_flagged(avd_ctx* ctx, const int* h_flags, int stride, int np)
     return m;
 }
 
+__global__ void k_wake() {}
+
 static void launch_records(avd_ctx* ctx, int p0, int np, int fa, const int* clipstart)
 {
     Workspace& ws = ctx->ws;
@@ -699,6 +701,8 @@ static int impl_analyze_batch_async(avd_ctx* ctx, const avd_clip* clips, int ncl
     }
     // pass 2: per clip, stage (host input) -> fused full-resolution kernel -> hash / Hamming, at the clip's offsets
     ctx->kmark_used = 0;
+    // profiling only: an empty launch in front of the first mark, so that the first region is the first kernel and not the queue's wake-up from idle as well
+    if (ctx->profiling) hipLaunchKernelGGL(k_wake, dim3(1), dim3(64), 0, ctx->stream);
     stage_mark(ctx, 0);
     int f0 = 0;
     size_t rb = 0, lp = 0, st = 0;
